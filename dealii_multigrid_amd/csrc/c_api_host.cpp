@@ -1,0 +1,212 @@
+// C ABI, host-side setup entry points (include/mgamd.h, section "Host-side setup").
+#include "api_common.hpp"
+
+using namespace mgamd;
+
+namespace mgamd
+{
+  thread_local std::string g_last_error;
+}
+
+extern "C" {
+
+const char *
+mgamd_last_error(void)
+{
+  return g_last_error.c_str();
+}
+
+const char *
+mgamd_version(void)
+{
+  return "mgamd 0.1 (gfx950)";
+}
+
+int
+mgamd_tria_create(const char *geometry, unsigned n_ref_global, unsigned n_ref_local, mgamd_tria **out)
+{
+  MGAMD_TRY
+  if (!geometry || !out)
+    throw std::invalid_argument("null argument");
+  auto *t = new mgamd_tria;
+  t->tria = std::make_shared<Tria>(Tria::create(geometry, n_ref_global, n_ref_local));
+  *out    = t;
+  MGAMD_CATCH
+}
+
+int
+mgamd_tria_coarsen(const mgamd_tria *fine, mgamd_tria **out)
+{
+  MGAMD_TRY
+  if (!fine || !out)
+    throw std::invalid_argument("null argument");
+  auto *t = new mgamd_tria;
+  t->tria = std::make_shared<Tria>(fine->tria->coarsen_global());
+  *out    = t;
+  MGAMD_CATCH
+}
+
+int
+mgamd_tria_destroy(mgamd_tria *t)
+{
+  delete t;
+  return MGAMD_OK;
+}
+
+int
+mgamd_tria_info(const mgamd_tria *t, uint64_t *n_cells, uint32_t *n_levels, uint64_t *n_cells_hn)
+{
+  MGAMD_TRY
+  if (!t)
+    throw std::invalid_argument("null argument");
+  if (n_cells)
+    *n_cells = t->tria->n_cells();
+  if (n_levels)
+    *n_levels = (uint32_t)t->tria->n_levels();
+  if (n_cells_hn)
+    *n_cells_hn = t->tria->n_cells_with_hanging_nodes();
+  MGAMD_CATCH
+}
+
+int
+mgamd_tria_get_cells(const mgamd_tria *t, uint8_t *level, uint32_t *i, uint32_t *j, uint32_t *k, uint16_t *mask)
+{
+  MGAMD_TRY
+  if (!t)
+    throw std::invalid_argument("null argument");
+  const auto &c = t->tria->cells;
+  for (size_t n = 0; n < c.size(); ++n)
+    {
+      if (level)
+        level[n] = c[n].level;
+      if (i)
+        i[n] = c[n].i;
+      if (j)
+        j[n] = c[n].j;
+      if (k)
+        k[n] = c[n].k;
+      if (mask)
+        mask[n] = t->tria->masks[n];
+    }
+  MGAMD_CATCH
+}
+
+int
+mgamd_dofs_create(const mgamd_tria *t, int degree, int max_brick, mgamd_dofs **out)
+{
+  MGAMD_TRY
+  if (!t || !out)
+    throw std::invalid_argument("null argument");
+  if (degree < 1 || degree > MAX_DEGREE)
+    throw std::invalid_argument("degree must be in [1," + std::to_string(MAX_DEGREE) + "]");
+  auto *d   = new mgamd_dofs;
+  d->tria   = t->tria;
+  d->tables = std::make_shared<LevelTables>(*d->tria, degree, max_brick);
+  *out      = d;
+  MGAMD_CATCH
+}
+
+int
+mgamd_dofs_destroy(mgamd_dofs *d)
+{
+  delete d;
+  return MGAMD_OK;
+}
+
+int
+mgamd_dofs_info(const mgamd_dofs *d, mgamd_dofs_info_t *info)
+{
+  MGAMD_TRY
+  if (!d || !info)
+    throw std::invalid_argument("null argument");
+  const LevelTables &L = *d->tables;
+  std::memset(info, 0, sizeof(*info));
+  info->degree      = L.p;
+  info->n_cells     = L.tria->n_cells();
+  info->n_dofs      = L.n_dofs;
+  info->n_interior  = L.n_interior;
+  info->n_tail      = L.n_tail;
+  info->n_dirichlet = L.n_dirichlet;
+  info->n_hanging   = L.n_hanging;
+  info->n_groups    = (uint32_t)L.groups.size();
+  for (size_t g = 0; g < L.groups.size() && g < 8; ++g)
+    {
+      info->group_B[g]     = L.groups[g].B;
+      info->group_slots[g] = L.groups[g].n_slots();
+    }
+  MGAMD_CATCH
+}
+
+int
+mgamd_dofs_get_keys(const mgamd_dofs *d, int32_t *keys)
+{
+  MGAMD_TRY
+  if (!d || !keys)
+    throw std::invalid_argument("null argument");
+  std::vector<DofKey> k;
+  d->tables->export_dof_keys(k);
+  static_assert(sizeof(DofKey) == 5 * sizeof(int32_t), "DofKey layout");
+  std::memcpy(keys, k.data(), k.size() * sizeof(DofKey));
+  MGAMD_CATCH
+}
+
+int
+mgamd_dofs_get_cell_dofs(const mgamd_dofs *d, uint32_t *out)
+{
+  MGAMD_TRY
+  if (!d || !out)
+    throw std::invalid_argument("null argument");
+  std::vector<uint32_t> v;
+  d->tables->export_cell_dofs(v);
+  std::memcpy(out, v.data(), v.size() * sizeof(uint32_t));
+  MGAMD_CATCH
+}
+
+int
+mgamd_dofs_rhs_constant(const mgamd_dofs *d, double *out)
+{
+  MGAMD_TRY
+  if (!d || !out)
+    throw std::invalid_argument("null argument");
+  std::vector<double> b;
+  d->tables->compute_rhs_constant(b);
+  std::memcpy(out, b.data(), b.size() * sizeof(double));
+  MGAMD_CATCH
+}
+
+int
+mgamd_transfer_tables_info(const mgamd_dofs *fine, const mgamd_dofs *coarse, uint64_t n_patches[3], uint32_t nf[3])
+{
+  MGAMD_TRY
+  if (!fine || !coarse)
+    throw std::invalid_argument("null argument");
+  TransferTables T(*fine->tables, *coarse->tables);
+  for (int k = 0; k < 3; ++k)
+    {
+      if (n_patches)
+        n_patches[k] = T.groups[k].n_patches();
+      if (nf)
+        nf[k] = T.groups[k].nf;
+    }
+  MGAMD_CATCH
+}
+
+int
+mgamd_transfer_tables_get(const mgamd_dofs *fine, const mgamd_dofs *coarse, int kind, uint32_t *coarse_idx, uint16_t *coarse_mask,
+                          uint32_t *fine_idx)
+{
+  MGAMD_TRY
+  if (!fine || !coarse || kind < 0 || kind > 2)
+    throw std::invalid_argument("bad argument");
+  TransferTables       T(*fine->tables, *coarse->tables);
+  const TransferGroup &g = T.groups[kind];
+  if (coarse_idx)
+    std::memcpy(coarse_idx, g.coarse_idx.data(), g.coarse_idx.size() * sizeof(uint32_t));
+  if (coarse_mask)
+    std::memcpy(coarse_mask, g.coarse_mask.data(), g.coarse_mask.size() * sizeof(uint16_t));
+  if (fine_idx)
+    std::memcpy(fine_idx, g.fine_idx.data(), g.fine_idx.size() * sizeof(uint32_t));
+  MGAMD_CATCH
+}
+
+} // extern "C"

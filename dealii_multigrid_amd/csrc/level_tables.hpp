@@ -1,0 +1,470 @@
+// Host-side level description: what deal.II's DoFHandler + AffineConstraints + MatrixFree::reinit
+// produce for one multigrid level in the reference (ref:include/operator.h:24-47,
+// ref:multigrid_throughput.cc:1578-1595), re-designed for a GPU with 160 KB of LDS per CU.
+//
+// Data layout:
+//  * The leaves are grouped into SLOTS: a slot is either a BRICK = complete uniform subtree of
+//    B^3 equal-size cells without hanging nodes (B a power of two, node lattice N = p*B+1 <= 17 per
+//    direction), or a single cell (B = 1, may carry hanging faces/edges).
+//  * DoFs are numbered  [ I | T | D | H ]:
+//      I  slot-interior DoFs (strictly inside a slot's node lattice; touched by that slot only),
+//         contiguous per slot in lattice-lexicographic order  -> implicit, coalesced addressing
+//      T  'tail': unconstrained DoFs on slot shells (shared between slots), in first-touch order
+//      D  Dirichlet DoFs (boundary id 0 = whole boundary, ref:multigrid_throughput.cc:1585-1591)
+//      H  hanging-node DoFs (own DoFs of fine faces/edges next to a coarser cell); like deal.II
+//         they are part of the vector (n_dofs parity) but only ever see the identity row
+//         (ref:include/operator.h:170-172).
+//  * A cell with hanging faces/edges gathers, like deal.II's matrix-free hanging-node path, the
+//    DoFs of the *parent* face/edge in the same local slot and then interpolates in-cell with
+//    the 1D matrices FE1D::I[c]; its configuration is Tria::masks.
+#pragma once
+#include "fe1d.hpp"
+#include "octree.hpp"
+
+namespace mgamd
+{
+  constexpr uint32_t INVALID_DOF = 0xFFFFFFFFu;
+
+  inline int
+  max_brick_for_degree(int p)
+  {
+    int B = 1;
+    while (2 * B * p + 1 <= 17)
+      B *= 2;
+    return B;
+  }
+
+  // position of lattice node (x,y,z) in the shell enumeration (lexicographic z,y,x skipping the interior)
+  inline int
+  shell_slot_of(int N, int x, int y, int z)
+  {
+    const int ring = N * N - (N - 2) * (N - 2);
+    if (z == 0)
+      return y * N + x;
+    if (z == N - 1)
+      return N * N + (N - 2) * ring + y * N + x;
+    int s = N * N + (z - 1) * ring;
+    if (y == 0)
+      return s + x;
+    if (y == N - 1)
+      return s + N + (N - 2) * 2 + x;
+    return s + N + (y - 1) * 2 + (x == 0 ? 0 : 1);
+  }
+
+  struct SlotGroup
+  {
+    int                   B = 1, N = 2, n_interior = 0, n_shell = 8;
+    std::vector<uint32_t> interior_base; // per slot: global index of its first interior DoF
+    std::vector<uint32_t> shell_idx;     // per slot x n_shell: global DoF or INVALID_DOF (Dirichlet)
+    std::vector<uint16_t> mask;          // per slot: constraint configuration (0 for bricks)
+    std::vector<double>   h;             // per slot: cell edge length
+    std::vector<uint32_t> first_cell;    // per slot: index of its first cell in Tria::cells
+    std::vector<uint16_t> shell_pos;     // n_shell: lattice index (z*N+y)*N+x of each shell entry
+    size_t
+    n_slots() const
+    {
+      return interior_base.size();
+    }
+  };
+
+  struct DofKey
+  {
+    int32_t px, py, pz, dirmask, level;
+  };
+
+  inline uint64_t
+  pack_key(uint32_t px, uint32_t py, uint32_t pz, int dm, int level)
+  {
+    return ((uint64_t)px << 43) | ((uint64_t)py << 25) | ((uint64_t)pz << 7) | ((uint64_t)dm << 4) | (uint64_t)(dm ? level : 0);
+  }
+  inline DofKey
+  unpack_key(uint64_t k)
+  {
+    return DofKey{(int32_t)(k >> 43), (int32_t)((k >> 25) & 0x3ffff), (int32_t)((k >> 7) & 0x3ffff), (int32_t)((k >> 4) & 7),
+                  (int32_t)(k & 15)};
+  }
+
+  // in-cell hanging-node interpolation (and its transpose) on (p+1)^3 gathered values
+  inline void
+  interpolate_hanging(const FE1D &fe, uint16_t mask, double *v, bool transpose)
+  {
+    if (!(mask >> MASK_FACE_SHIFT))
+      return;
+    const int p = fe.p, n = p + 1;
+    const int cp[3]     = {mask & 1, (mask >> 1) & 1, (mask >> 2) & 1};
+    const int stride[3] = {1, n, n * n};
+    double    tmp[MAX_DEGREE + 1];
+    for (int dd = 0; dd < 3; ++dd)
+      {
+        const int     d = transpose ? 2 - dd : dd;
+        const int     e = (d + 1) % 3, f = (d + 2) % 3;
+        const bool    fe_c = (mask >> (MASK_FACE_SHIFT + e)) & 1, ff_c = (mask >> (MASK_FACE_SHIFT + f)) & 1,
+                   ed_c    = (mask >> (MASK_EDGE_SHIFT + d)) & 1;
+        const double *Ic   = fe.I[cp[d]].data();
+        for (int ae = 0; ae < n; ++ae)
+          for (int af = 0; af < n; ++af)
+            {
+              const bool on_e = ae == cp[e] * p, on_f = af == cp[f] * p;
+              if (!((fe_c && on_e) || (ff_c && on_f) || (ed_c && on_e && on_f)))
+                continue;
+              double *line = v + ae * stride[e] + af * stride[f];
+              for (int a = 0; a < n; ++a)
+                {
+                  double s = 0;
+                  for (int b = 0; b < n; ++b)
+                    s += (transpose ? Ic[b * n + a] : Ic[a * n + b]) * line[b * stride[d]];
+                  tmp[a] = s;
+                }
+              for (int a = 0; a < n; ++a)
+                line[a * stride[d]] = tmp[a];
+            }
+      }
+  }
+
+  class LevelTables
+  {
+  public:
+    int                    p = 1;
+    const Tria            *tria = nullptr;
+    FE1D                   fe;
+    std::vector<SlotGroup> groups; // one per brick size, largest first; last = single cells
+    uint32_t               n_dofs = 0, n_interior = 0, n_tail = 0, n_dirichlet = 0, n_hanging = 0;
+    // per cell: group, slot-in-group
+    std::vector<uint8_t>  cell_group;
+    std::vector<uint32_t> cell_slot;
+    FlatMap               keymap; // packed key -> global index (T, D, H DoFs only)
+
+    LevelTables(const Tria &t, int degree, int max_brick = 0)
+      : p(degree)
+      , tria(&t)
+      , fe(degree)
+    {
+      build(max_brick > 0 ? std::min(max_brick, max_brick_for_degree(p)) : max_brick_for_degree(p));
+    }
+
+    uint32_t
+    first_constrained() const
+    {
+      return n_interior + n_tail;
+    }
+
+    // is local node (a,b,c) of a masked cell on one of its hanging faces/edges?
+    static bool
+    node_on_constrained_entity(uint16_t mask, int p, const int a[3], bool *parent_corner = nullptr)
+    {
+      const int cp[3] = {mask & 1, (mask >> 1) & 1, (mask >> 2) & 1};
+      bool      on[3];
+      for (int d = 0; d < 3; ++d)
+        on[d] = a[d] == cp[d] * p;
+      if (parent_corner)
+        *parent_corner = on[0] && on[1] && on[2];
+      for (int d = 0; d < 3; ++d)
+        {
+          if (((mask >> (MASK_FACE_SHIFT + d)) & 1) && on[d])
+            return true;
+          if (((mask >> (MASK_EDGE_SHIFT + d)) & 1) && on[(d + 1) % 3] && on[(d + 2) % 3])
+            return true;
+        }
+      return false;
+    }
+
+    // key of the DoF that cell `ci` gathers at local node a (parent-resolved for hanging entities)
+    uint64_t
+    resolved_key(size_t ci, const int a[3]) const
+    {
+      const Cell    &c    = tria->cells[ci];
+      const uint16_t mask = tria->masks[ci];
+      if ((mask >> MASK_FACE_SHIFT) && node_on_constrained_entity(mask, p, a))
+        return own_key(Cell{c.i >> 1, c.j >> 1, c.k >> 1, (uint8_t)(c.level - 1)}, a);
+      return own_key(c, a);
+    }
+    uint64_t
+    own_key(const Cell &c, const int a[3]) const
+    {
+      const uint32_t S  = 1u << (LMAX - c.level);
+      const int      dm = (a[0] % p ? 1 : 0) | (a[1] % p ? 2 : 0) | (a[2] % p ? 4 : 0);
+      return pack_key((c.i * p + a[0]) * S, (c.j * p + a[1]) * S, (c.k * p + a[2]) * S, dm, c.level);
+    }
+    bool
+    key_on_boundary(uint64_t key) const
+    {
+      const DofKey   k   = unpack_key(key);
+      const int32_t  top = p << LMAX;
+      return k.px == 0 || k.py == 0 || k.pz == 0 || k.px == top || k.py == top || k.pz == top;
+    }
+
+    // global DoF index gathered by cell ci at local node (a0,a1,a2); INVALID_DOF for Dirichlet.
+    // *constrained: node lies on a hanging face/edge (index then refers to the parent entity's DoF)
+    uint32_t
+    cell_node_index(size_t ci, const int a[3], bool *constrained = nullptr, bool *parent_corner = nullptr) const
+    {
+      const SlotGroup &g    = groups[cell_group[ci]];
+      const uint32_t   s    = cell_slot[ci];
+      const Cell      &c    = tria->cells[ci];
+      const uint16_t   mask = tria->masks[ci];
+      if (constrained)
+        *constrained = (mask >> MASK_FACE_SHIFT) ? node_on_constrained_entity(mask, p, a, parent_corner) : false;
+      const int x = (c.i & (g.B - 1)) * p + a[0], y = (c.j & (g.B - 1)) * p + a[1], z = (c.k & (g.B - 1)) * p + a[2];
+      const int N = g.N;
+      if (x > 0 && y > 0 && z > 0 && x < N - 1 && y < N - 1 && z < N - 1)
+        return g.interior_base[s] + ((z - 1) * (N - 2) + (y - 1)) * (N - 2) + (x - 1);
+      return g.shell_idx[(size_t)s * g.n_shell + shell_slot_of(N, x, y, z)];
+    }
+
+    // full per-cell table (resolved indices, x fastest), for the CPU oracle and tests
+    void
+    export_cell_dofs(std::vector<uint32_t> &out) const
+    {
+      const int n = p + 1;
+      out.resize(tria->cells.size() * n * n * n);
+      size_t t = 0;
+      for (size_t ci = 0; ci < tria->cells.size(); ++ci)
+        for (int c = 0; c < n; ++c)
+          for (int b = 0; b < n; ++b)
+            for (int a = 0; a < n; ++a)
+              {
+                const int l[3] = {a, b, c};
+                out[t++]       = cell_node_index(ci, l);
+              }
+    }
+
+    // geometric identity of every DoF (for matching against an independently numbered oracle)
+    void
+    export_dof_keys(std::vector<DofKey> &out) const
+    {
+      out.assign(n_dofs, DofKey{-1, -1, -1, -1, -1});
+      for (const SlotGroup &g : groups)
+        for (size_t s = 0; s < g.n_slots(); ++s)
+          {
+            const Cell &c = tria->cells[g.first_cell[s]];
+            const Cell  anchor{c.i & ~(uint32_t)(g.B - 1), c.j & ~(uint32_t)(g.B - 1), c.k & ~(uint32_t)(g.B - 1), c.level};
+            const int   N = g.N;
+            for (int z = 1; z < N - 1; ++z)
+              for (int y = 1; y < N - 1; ++y)
+                for (int x = 1; x < N - 1; ++x)
+                  {
+                    const int a[3] = {x, y, z};
+                    out[g.interior_base[s] + ((z - 1) * (N - 2) + (y - 1)) * (N - 2) + (x - 1)] = unpack_key(own_key(anchor, a));
+                  }
+          }
+      keymap_for_each([&](uint64_t key, int32_t idx) {
+        DofKey k = unpack_key(key);
+        out[idx] = k;
+      });
+    }
+
+    // right-hand side for f == 1, homogeneous Dirichlet data (ref:include/operator.h:362-413;
+    // the lifting of ref:include/operator.h:415-446 vanishes for g == 0)
+    void
+    compute_rhs_constant(std::vector<double> &b) const
+    {
+      b.assign(n_dofs, 0.0);
+      const int n = p + 1;
+      for (const SlotGroup &g : groups)
+        {
+          const int           N = g.N;
+          std::vector<double> m1(N, 0.0); // assembled 1D load vector over the brick line
+          for (int cb = 0; cb < g.B; ++cb)
+            for (int a = 0; a < n; ++a)
+              m1[cb * p + a] += fe.m[a];
+          std::vector<double> loc((size_t)N * N * N);
+          for (size_t s = 0; s < g.n_slots(); ++s)
+            {
+              const double h3 = g.h[s] * g.h[s] * g.h[s];
+              for (int z = 0; z < N; ++z)
+                for (int y = 0; y < N; ++y)
+                  for (int x = 0; x < N; ++x)
+                    loc[(z * N + y) * N + x] = h3 * m1[x] * m1[y] * m1[z];
+              if (g.B == 1)
+                interpolate_hanging(fe, g.mask[s], loc.data(), true);
+              for (int z = 0; z < N; ++z)
+                for (int y = 0; y < N; ++y)
+                  for (int x = 0; x < N; ++x)
+                    {
+                      uint32_t idx;
+                      if (x > 0 && y > 0 && z > 0 && x < N - 1 && y < N - 1 && z < N - 1)
+                        idx = g.interior_base[s] + ((z - 1) * (N - 2) + (y - 1)) * (N - 2) + (x - 1);
+                      else
+                        idx = g.shell_idx[s * g.n_shell + shell_slot_of(N, x, y, z)];
+                      if (idx != INVALID_DOF)
+                        b[idx] += loc[(z * N + y) * N + x];
+                    }
+            }
+        }
+    }
+
+    template <class F>
+    void
+    keymap_for_each(F f) const
+    {
+      for (size_t t = 0; t < key_list.size(); ++t)
+        f(key_list[t], key_index[t]);
+    }
+
+  private:
+    std::vector<uint64_t> key_list;  // keys of T/D/H DoFs in creation order
+    std::vector<int32_t>  key_index; // their final global indices
+
+    void
+    build(int Bmax)
+    {
+      const auto  &cells = tria->cells;
+      const auto  &masks = tria->masks;
+      const size_t nc    = cells.size();
+      // ---- 1. slot decomposition
+      std::vector<int> sizes;
+      for (int B = Bmax; B >= 1; B /= 2)
+        sizes.push_back(B);
+      groups.resize(sizes.size());
+      cell_group.assign(nc, 0xFF);
+      cell_slot.assign(nc, 0);
+      for (size_t gi = 0; gi < sizes.size(); ++gi)
+        {
+          SlotGroup &g = groups[gi];
+          g.B          = sizes[gi];
+          g.N          = p * g.B + 1;
+          g.n_interior = (g.N - 2) * (g.N - 2) * (g.N - 2);
+          g.n_shell    = g.N * g.N * g.N - g.n_interior;
+          g.shell_pos.resize(g.n_shell);
+          for (int z = 0; z < g.N; ++z)
+            for (int y = 0; y < g.N; ++y)
+              for (int x = 0; x < g.N; ++x)
+                if (!(x > 0 && y > 0 && z > 0 && x < g.N - 1 && y < g.N - 1 && z < g.N - 1))
+                  g.shell_pos[shell_slot_of(g.N, x, y, z)] = (uint16_t)((z * g.N + y) * g.N + x);
+          const int    B  = g.B;
+          const size_t B3 = (size_t)B * B * B;
+          int          b  = 0;
+          while ((1 << b) < B)
+            ++b;
+          size_t t = 0;
+          while (t < nc)
+            {
+              if (cell_group[t] != 0xFF)
+                {
+                  ++t;
+                  continue;
+                }
+              const Cell &c = cells[t];
+              bool        ok;
+              if (B == 1)
+                ok = true;
+              else
+                {
+                  ok = c.level >= b && !(c.i & (B - 1)) && !(c.j & (B - 1)) && !(c.k & (B - 1)) && t + B3 <= nc;
+                  for (size_t s = 0; ok && s < B3; ++s)
+                    {
+                      const Cell &d = cells[t + s];
+                      ok = d.level == c.level && (d.i >> b) == (c.i >> b) && (d.j >> b) == (c.j >> b) && (d.k >> b) == (c.k >> b) &&
+                           !(masks[t + s] >> MASK_FACE_SHIFT) && cell_group[t + s] == 0xFF;
+                    }
+                }
+              if (!ok)
+                {
+                  ++t;
+                  continue;
+                }
+              const uint32_t slot = (uint32_t)g.first_cell.size();
+              g.first_cell.push_back((uint32_t)t);
+              g.mask.push_back(B == 1 ? masks[t] : 0);
+              g.h.push_back(2.0 / (double)(1u << c.level));
+              for (size_t s = 0; s < B3; ++s)
+                {
+                  cell_group[t + s] = (uint8_t)gi;
+                  cell_slot[t + s]  = slot;
+                }
+              t += B3;
+            }
+          g.interior_base.assign(g.first_cell.size(), 0);
+          g.shell_idx.assign(g.first_cell.size() * (size_t)g.n_shell, INVALID_DOF);
+        }
+      // ---- 2. interior numbering, slots in Morton order of their first cell
+      struct Ref
+      {
+        uint32_t first_cell, group, slot;
+      };
+      std::vector<Ref> order;
+      for (size_t gi = 0; gi < groups.size(); ++gi)
+        for (size_t s = 0; s < groups[gi].n_slots(); ++s)
+          order.push_back(Ref{groups[gi].first_cell[s], (uint32_t)gi, (uint32_t)s});
+      std::sort(order.begin(), order.end(), [](const Ref &a, const Ref &b) { return a.first_cell < b.first_cell; });
+      uint64_t next = 0;
+      for (const Ref &r : order)
+        {
+          groups[r.group].interior_base[r.slot] = (uint32_t)next;
+          next += groups[r.group].n_interior;
+        }
+      if (next > 0xFFFFFFF0ull)
+        throw std::runtime_error("level exceeds 32-bit DoF indices");
+      n_interior = (uint32_t)next;
+      // ---- 3. shell DoFs: class 0 tail, 1 Dirichlet, 2 hanging; provisional id = (class<<30 | counter)
+      keymap.erase_all_and_reserve(1024);
+      uint32_t counter[3] = {0, 0, 0};
+      auto     classify   = [&](uint64_t key, int cls) -> int32_t {
+        bool     ins;
+        int32_t *v = keymap.insert(key, 0, &ins);
+        if (ins)
+          {
+            *v = (int32_t)(((uint32_t)cls << 30) | counter[cls]++);
+            key_list.push_back(key);
+          }
+        return *v;
+      };
+      for (const Ref &r : order)
+        {
+          SlotGroup   &g = groups[r.group];
+          const size_t ci = g.first_cell[r.slot];
+          const Cell  &c  = cells[ci];
+          const Cell   anchor{c.i & ~(uint32_t)(g.B - 1), c.j & ~(uint32_t)(g.B - 1), c.k & ~(uint32_t)(g.B - 1), c.level};
+          for (int s = 0; s < g.n_shell; ++s)
+            {
+              const int lin  = g.shell_pos[s];
+              const int a[3] = {lin % g.N, (lin / g.N) % g.N, lin / (g.N * g.N)};
+              const uint64_t key = g.B == 1 ? resolved_key(ci, a) : own_key(anchor, a);
+              const int32_t  id  = classify(key, key_on_boundary(key) ? 1 : 0);
+              g.shell_idx[(size_t)r.slot * g.n_shell + s] = (uint32_t)id; // provisional
+            }
+        }
+      // own DoFs of hanging faces/edges
+      {
+        const SlotGroup &g = groups.back();
+        for (size_t s = 0; s < g.n_slots(); ++s)
+          if (g.mask[s] >> MASK_FACE_SHIFT)
+            {
+              const size_t ci = g.first_cell[s];
+              for (int z = 0; z <= p; ++z)
+                for (int y = 0; y <= p; ++y)
+                  for (int x = 0; x <= p; ++x)
+                    {
+                      const int a[3] = {x, y, z};
+                      bool      corner;
+                      if (node_on_constrained_entity(g.mask[s], p, a, &corner) && !corner)
+                        {
+                          const uint64_t key = own_key(cells[ci], a);
+                          if (!keymap.find(key))
+                            classify(key, 2);
+                        }
+                    }
+            }
+      }
+      n_tail      = counter[0];
+      n_dirichlet = counter[1];
+      n_hanging   = counter[2];
+      const uint64_t total = (uint64_t)n_interior + n_tail + n_dirichlet + n_hanging;
+      if (total > 0xFFFFFFF0ull)
+        throw std::runtime_error("level exceeds 32-bit DoF indices");
+      n_dofs                 = (uint32_t)total;
+      const uint32_t base[3] = {n_interior, n_interior + n_tail, n_interior + n_tail + n_dirichlet};
+      auto           final_index = [&](uint32_t prov) { return base[prov >> 30] + (prov & 0x3FFFFFFFu); };
+      key_index.resize(key_list.size());
+      for (size_t t = 0; t < key_list.size(); ++t)
+        {
+          int32_t *v   = keymap.find(key_list[t]);
+          *v           = (int32_t)final_index((uint32_t)*v);
+          key_index[t] = *v;
+        }
+      for (SlotGroup &g : groups)
+        for (uint32_t &v : g.shell_idx)
+          v = (v >> 30) == 1 ? INVALID_DOF : final_index(v);
+    }
+  };
+} // namespace mgamd

@@ -1,0 +1,191 @@
+/* mgamd.h -- C ABI of the MI355X-native matrix-free multigrid V-cycle.
+ *
+ * Drop-in boundary for the hot path of peterrum/dealii-multigrid's multigrid_throughput.cc.
+ * The reference has no FFI: its path sits behind deal.II's duck-typed C++ template concepts
+ * (SURVEY.md section 8b).  Every entry point below names the reference interface it replaces; the
+ * header-only C++ layer `dealii_multigrid_amd/csrc/mgamd.hpp` re-exposes them as classes with
+ * deal.II's method names (Operator::vmult, PreconditionChebyshev::vmult/step,
+ * MGTwoLevelTransfer::prolongate_and_add, PreconditionMG::vmult, SolverCG::solve ...).
+ *
+ * Conventions: every function returns 0 on success and a non-zero status on failure, never
+ * throws across the ABI; `mgamd_last_error()` returns the message of the calling thread's last
+ * failure.  Every *_create has a *_destroy.  Vectors are device resident and owned by the library;
+ * host transfer is explicit.  Calls on one context are ordered on that context's HIP stream and
+ * are asynchronous unless they return data to the host.  One host thread per context.
+ * Device functions fail with status MGAMD_ERR_NO_DEVICE when no gfx950 device is usable: there is
+ * no CPU fallback in this library.
+ */
+#ifndef MGAMD_H
+#define MGAMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGAMD_OK 0
+#define MGAMD_ERR 1
+#define MGAMD_ERR_NO_DEVICE 2
+#define MGAMD_ERR_INVALID 3
+
+#define MGAMD_INVALID_DOF 0xFFFFFFFFu
+
+typedef struct mgamd_ctx       mgamd_ctx;       /* device + stream (+ communicator)                    */
+typedef struct mgamd_tria      mgamd_tria;      /* octree mesh  <-> parallel::distributed::Triangulation */
+typedef struct mgamd_dofs      mgamd_dofs;      /* DoFHandler + AffineConstraints + MatrixFree tables    */
+typedef struct mgamd_vec       mgamd_vec;       /* LinearAlgebra::distributed::Vector<Number>            */
+typedef struct mgamd_level_op  mgamd_level_op;  /* Operator<3,1,Number>  (ref:include/operator.h:11)    */
+typedef struct mgamd_cheb      mgamd_cheb;      /* PreconditionChebyshev<Operator,Vector,DiagonalMatrix> */
+typedef struct mgamd_transfer2 mgamd_transfer2; /* MGTwoLevelTransfer<3,Vector>                          */
+typedef struct mgamd_mg        mgamd_mg;        /* Multigrid + PreconditionMG + MGTransferGlobalCoarsening */
+
+const char *mgamd_last_error(void);
+const char *mgamd_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Host-side setup (no GPU needed)
+ * ------------------------------------------------------------------------------------------- */
+
+/* GridGenerator::{hyper_cube+refine_global, create_quadrant, create_quadrant_flexible,
+ * create_annulus, create_circle}: ref:multigrid_throughput.cc:2048-2062, ref:include/grid_generator.h.
+ * geometry in {"hypercube","quadrant","quadrant_flexible","annulus","circle"}. */
+int mgamd_tria_create(const char *geometry, unsigned n_ref_global, unsigned n_ref_local, mgamd_tria **out);
+/* one level of MGTransferGlobalCoarseningTools::create_geometric_coarsening_sequence
+ * (ref:multigrid_throughput.cc:2219-2224): coarsen every family once, re-balance. */
+int mgamd_tria_coarsen(const mgamd_tria *fine, mgamd_tria **out);
+int mgamd_tria_destroy(mgamd_tria *t);
+/* n_global_active_cells(), n_global_levels(), cells with a coarser face/edge neighbour
+ * (table columns n_cells / n_cells_hn: ref:multigrid_throughput.cc:2177-2190, 2329-2331). */
+int mgamd_tria_info(const mgamd_tria *t, uint64_t *n_cells, uint32_t *n_levels, uint64_t *n_cells_hn);
+/* leaves in Morton (p4est) order; arrays of n_cells entries, any may be NULL */
+int mgamd_tria_get_cells(const mgamd_tria *t, uint8_t *level, uint32_t *i, uint32_t *j, uint32_t *k, uint16_t *mask);
+
+typedef struct
+{
+  uint32_t degree;
+  uint64_t n_cells;
+  uint32_t n_dofs;      /* DoFHandler::n_dofs()                                              */
+  uint32_t n_interior;  /* [0, n_interior): slot-interior DoFs, contiguous per slot          */
+  uint32_t n_tail;      /* then the shared unconstrained DoFs                                */
+  uint32_t n_dirichlet; /* then Dirichlet DoFs                                               */
+  uint32_t n_hanging;   /* then hanging-node DoFs                                            */
+  uint32_t n_groups;    /* slot groups (brick sizes)                                         */
+  uint32_t group_B[8];  /* cells per direction of each group's bricks                        */
+  uint64_t group_slots[8];
+} mgamd_dofs_info_t;
+
+/* DoFHandler::distribute_dofs(FE_Q(degree)) + zero Dirichlet on boundary id 0 + hanging-node
+ * constraints + MatrixFree::reinit tables (ref:multigrid_throughput.cc:1578-1595,
+ * ref:include/operator.h:24-47).  max_brick = 0 selects the largest brick that fits LDS;
+ * max_brick = 1 disables bricks (every cell a generic slot). */
+int mgamd_dofs_create(const mgamd_tria *t, int degree, int max_brick, mgamd_dofs **out);
+int mgamd_dofs_destroy(mgamd_dofs *d);
+int mgamd_dofs_info(const mgamd_dofs *d, mgamd_dofs_info_t *info);
+/* geometric identity of each DoF: keys[5*i..] = {px,py,pz,dirmask,level} (tests / oracle matching) */
+int mgamd_dofs_get_keys(const mgamd_dofs *d, int32_t *keys);
+/* per cell (p+1)^3 gathered DoF indices, x fastest; hanging entities resolved to the parent's
+ * DoFs; MGAMD_INVALID_DOF marks Dirichlet DoFs */
+int mgamd_dofs_get_cell_dofs(const mgamd_dofs *d, uint32_t *out);
+/* Operator::rhs for f == 1, g == 0 (ref:include/operator.h:362-447, ref:multigrid_throughput.cc:2286-2291) */
+int mgamd_dofs_rhs_constant(const mgamd_dofs *d, double *out);
+
+/* raw two-level transfer tables (for the CPU oracle): kind 0 identity, 1 h-embedding, 2 p-embedding */
+int mgamd_transfer_tables_info(const mgamd_dofs *fine, const mgamd_dofs *coarse, uint64_t n_patches[3], uint32_t nf[3]);
+int mgamd_transfer_tables_get(const mgamd_dofs *fine, const mgamd_dofs *coarse, int kind, uint32_t *coarse_idx,
+                              uint16_t *coarse_mask, uint32_t *fine_idx);
+
+/* ---------------------------------------------------------------------------------------------
+ * Device runtime
+ * ------------------------------------------------------------------------------------------- */
+int mgamd_ctx_create(int device, mgamd_ctx **out);
+int mgamd_ctx_destroy(mgamd_ctx *ctx);
+int mgamd_ctx_synchronize(mgamd_ctx *ctx);
+/* the HIP stream all work of this context is submitted to (hipStream_t as void*) */
+int mgamd_ctx_stream(mgamd_ctx *ctx, void **stream);
+
+/* number_type: 8 = double, 4 = float (MGNumberType, ref:multigrid_throughput.cc:2430-2433) */
+#define MGAMD_F64 8
+#define MGAMD_F32 4
+
+/* Vectors (LinearAlgebra::distributed::Vector: ref:include/operator.h:17) */
+int mgamd_vec_create(mgamd_ctx *ctx, uint64_t n, int number_type, mgamd_vec **out);
+int mgamd_vec_destroy(mgamd_vec *v);
+int mgamd_vec_size(const mgamd_vec *v, uint64_t *n);
+int mgamd_vec_from_host(mgamd_vec *v, const double *src); /* casts when the vector is float */
+int mgamd_vec_to_host(const mgamd_vec *v, double *dst);
+int mgamd_vec_set(mgamd_vec *v, double value);                       /* v = value               */
+int mgamd_vec_copy(mgamd_vec *dst, const mgamd_vec *src);            /* dst = src (casts)       */
+int mgamd_vec_axpy(mgamd_vec *y, double a, const mgamd_vec *x);      /* y += a x                */
+int mgamd_vec_sadd(mgamd_vec *y, double s, double a, const mgamd_vec *x); /* y = s y + a x      */
+int mgamd_vec_dot(const mgamd_vec *x, const mgamd_vec *y, double *result);
+int mgamd_vec_norm2(const mgamd_vec *x, double *result);
+
+/* Operator::reinit (ref:include/operator.h:24-47) */
+int mgamd_level_op_create(mgamd_ctx *ctx, const mgamd_dofs *dofs, int number_type, mgamd_level_op **out);
+int mgamd_level_op_destroy(mgamd_level_op *op);
+int mgamd_level_op_m(const mgamd_level_op *op, uint64_t *n); /* Operator::m (ref:include/operator.h:123) */
+/* Operator::initialize_dof_vector (ref:include/operator.h:140) */
+int mgamd_level_op_init_vector(const mgamd_level_op *op, mgamd_vec **out);
+/* Operator::vmult: dst = A src, identity on constrained rows (ref:include/operator.h:152-183) */
+int mgamd_level_op_vmult(mgamd_level_op *op, mgamd_vec *dst, const mgamd_vec *src);
+/* Operator::compute_inverse_diagonal (ref:include/operator.h:228-242) */
+int mgamd_level_op_inverse_diagonal(mgamd_level_op *op, mgamd_vec *diagonal);
+/* Operator::rhs with f == 1, g == 0 (ref:include/operator.h:362-447) */
+int mgamd_level_op_rhs(mgamd_level_op *op, mgamd_vec *rhs);
+
+/* PreconditionChebyshev (ref:multigrid_throughput.cc:849-852, 867-883): the inverse diagonal is
+ * computed internally (DiagonalMatrix preconditioner); eigenvalues are estimated at creation with
+ * eig_cg_n_iterations CG steps, max *= 1.2, min = max / smoothing_range. */
+int mgamd_cheb_create(mgamd_level_op *op, unsigned degree, double smoothing_range, unsigned eig_cg_n_iterations,
+                      mgamd_cheb **out);
+int mgamd_cheb_destroy(mgamd_cheb *c);
+int mgamd_cheb_vmult(mgamd_cheb *c, mgamd_vec *dst, const mgamd_vec *src); /* zero start: MGSmoother::apply  */
+int mgamd_cheb_step(mgamd_cheb *c, mgamd_vec *dst, const mgamd_vec *src);  /* general start: MGSmoother::smooth */
+int mgamd_cheb_get_eigen_estimates(const mgamd_cheb *c, double *min_eigenvalue, double *max_eigenvalue);
+
+/* MGTwoLevelTransfer::reinit(dof_fine, dof_coarse, constraint_fine, constraint_coarse)
+ * (ref:multigrid_throughput.cc:1600-1604) */
+int mgamd_transfer2_create(mgamd_level_op *fine, mgamd_level_op *coarse, mgamd_transfer2 **out);
+int mgamd_transfer2_destroy(mgamd_transfer2 *t);
+int mgamd_transfer2_prolongate_and_add(mgamd_transfer2 *t, mgamd_vec *dst_fine, const mgamd_vec *src_coarse);
+int mgamd_transfer2_restrict_and_add(mgamd_transfer2 *t, mgamd_vec *dst_coarse, const mgamd_vec *src_fine);
+
+/* Multigrid + PreconditionMG over MGTransferGlobalCoarsening (ref:multigrid_throughput.cc:1093-1133,
+ * 1618-1621).  levels[0] is the coarsest; transfers[l] connects levels l-1 and l (transfers[0] unused,
+ * may be NULL); smoothers[0] is only used by coarse solver "cg_with_chebyshev".
+ * coarse_solver in {"direct","cg","cg_with_chebyshev"} (ref:multigrid_throughput.cc:911-944; the
+ * Trilinos/PETSc AMG choices map to "direct"). */
+int mgamd_mg_create(mgamd_ctx *ctx, unsigned n_levels, mgamd_level_op *const *levels, mgamd_transfer2 *const *transfers,
+                    mgamd_cheb *const *smoothers, const char *coarse_solver, mgamd_mg **out);
+int mgamd_mg_destroy(mgamd_mg *mg);
+/* PreconditionMG::vmult: z = V-cycle(r)  (ref:multigrid_throughput.cc:1132-1133) -- the metric's unit of work.
+ * z and r are vectors of the finest level's outer number type (double). */
+int mgamd_mg_vcycle(mgamd_mg *mg, mgamd_vec *z, const mgamd_vec *r);
+/* Multigrid::connect_{pre_smoother_step,residual_step,restriction,coarse_solve,prolongation,
+ * edge_prolongation,post_smoother_step} + PreconditionMG::connect_transfer_to_{mg,global}
+ * (ref:multigrid_throughput.cc:1183-1192, 1233-1234).  stage 0..6 as in the reference's timer index,
+ * 7 = transfer_to_mg, 8 = transfer_to_global.  With a callback installed the V-cycle runs eagerly
+ * and synchronises the stream around every stage so host clocks are meaningful. */
+typedef void (*mgamd_stage_callback)(int stage, int start, unsigned level, void *user);
+int mgamd_mg_set_stage_callback(mgamd_mg *mg, mgamd_stage_callback cb, void *user);
+/* run `n` V-cycles back to back and return the average time per cycle in milliseconds, measured
+ * with HIP events on the context's stream (bench.py / harness). use_graph != 0 replays a captured
+ * hipGraph of one cycle. */
+int mgamd_mg_time_vcycles(mgamd_mg *mg, mgamd_vec *z, const mgamd_vec *r, unsigned n, int use_graph, double *ms_per_cycle);
+
+/* SolverCG + ReductionControl with PreconditionMG (ref:multigrid_throughput.cc:1140-1147, 1238-1254,
+ * 1625-1635): solves A x = b from x = 0; returns last_step() and the final residual norm. */
+int mgamd_solve_cg(mgamd_level_op *A, mgamd_mg *preconditioner, mgamd_vec *x, const mgamd_vec *b, double reltol, double abstol,
+                   unsigned maxiter, unsigned *n_iterations, double *residual_norm);
+
+/* per-kernel device time of the dominant kernel (cell operator) accumulated since the last reset,
+ * measured with HIP events when profiling is enabled (bench.py roofline.achieved) */
+int mgamd_ctx_kernel_profile(mgamd_ctx *ctx, int enable);
+int mgamd_ctx_kernel_profile_read(mgamd_ctx *ctx, double *total_ms, uint64_t *n_launches, double *algorithmic_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGAMD_H */
