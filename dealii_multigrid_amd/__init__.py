@@ -1,0 +1,398 @@
+"""MI355X-native matrix-free multigrid V-cycle -- Python host mirror of the reference's plugin surface.
+
+Thin ctypes layer over the C ABI (`include/mgamd.h`, `lib/libmgamd.so`).  Class and method names
+follow deal.II as the reference uses it:
+
+  Triangulation            <-> parallel::distributed::Triangulation + GridGenerator  (ref:multigrid_throughput.cc:2041-2062)
+  DoFs                     <-> DoFHandler + AffineConstraints + MatrixFree tables      (ref:multigrid_throughput.cc:1578-1595)
+  Operator                 <-> Operator<3,1,Number>                                    (ref:include/operator.h:11-557)
+  PreconditionChebyshev    <-> PreconditionChebyshev<Operator,Vector,DiagonalMatrix>   (ref:multigrid_throughput.cc:849-883)
+  MGTwoLevelTransfer       <-> MGTwoLevelTransfer<3,Vector>                            (ref:multigrid_throughput.cc:1600-1604)
+  PreconditionMG           <-> Multigrid + PreconditionMG + MGTransferGlobalCoarsening (ref:multigrid_throughput.cc:1093-1133)
+  solve_cg                 <-> SolverCG + ReductionControl                             (ref:multigrid_throughput.cc:1140-1147)
+  solve_with_global_coarsening  (ref:multigrid_throughput.cc:1443-1666)
+
+There is no CPU fallback: every device call raises if the HIP library or a gfx950 GPU is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmgamd.so")
+F64, F32 = 8, 4
+INVALID_DOF = 0xFFFFFFFF
+
+
+class MgamdError(RuntimeError):
+    pass
+
+
+class NoDeviceError(MgamdError):
+    pass
+
+
+def _load():
+    if not os.path.exists(_LIB_PATH):
+        raise MgamdError(
+            f"{_LIB_PATH} is missing: build it with `make` (or __graft_entry__.build()); there is no fallback path"
+        )
+    lib = C.CDLL(_LIB_PATH)
+    lib.mgamd_last_error.restype = C.c_char_p
+    lib.mgamd_version.restype = C.c_char_p
+    return lib
+
+
+_lib = _load()
+
+
+def _chk(status):
+    if status != 0:
+        msg = _lib.mgamd_last_error().decode()
+        if status == 2:
+            raise NoDeviceError(msg)
+        raise MgamdError(msg)
+
+
+class DofsInfo(C.Structure):
+    _fields_ = [
+        ("degree", C.c_uint32),
+        ("n_cells", C.c_uint64),
+        ("n_dofs", C.c_uint32),
+        ("n_interior", C.c_uint32),
+        ("n_tail", C.c_uint32),
+        ("n_dirichlet", C.c_uint32),
+        ("n_hanging", C.c_uint32),
+        ("n_groups", C.c_uint32),
+        ("group_B", C.c_uint32 * 8),
+        ("group_slots", C.c_uint64 * 8),
+    ]
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Triangulation:
+    def __init__(self, geometry="hypercube", n_ref_global=0, n_ref_local=0, _handle=None):
+        self._h = C.c_void_p()
+        if _handle is not None:
+            self._h = _handle
+        else:
+            _chk(_lib.mgamd_tria_create(geometry.encode(), C.c_uint(n_ref_global), C.c_uint(n_ref_local), C.byref(self._h)))
+        nc, nl, nh = C.c_uint64(), C.c_uint32(), C.c_uint64()
+        _chk(_lib.mgamd_tria_info(self._h, C.byref(nc), C.byref(nl), C.byref(nh)))
+        self.n_cells, self.n_levels, self.n_cells_hn = nc.value, nl.value, nh.value
+
+    def coarsen(self) -> "Triangulation":
+        h = C.c_void_p()
+        _chk(_lib.mgamd_tria_coarsen(self._h, C.byref(h)))
+        return Triangulation(_handle=h)
+
+    def cells(self):
+        n = self.n_cells
+        lev = np.zeros(n, np.uint8)
+        i, j, k = (np.zeros(n, np.uint32) for _ in range(3))
+        mask = np.zeros(n, np.uint16)
+        _chk(_lib.mgamd_tria_get_cells(self._h, _ptr(lev), _ptr(i), _ptr(j), _ptr(k), _ptr(mask)))
+        return lev, i, j, k, mask
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.mgamd_tria_destroy(self._h)
+            self._h = None
+
+
+def create_geometric_coarsening_sequence(fine: Triangulation):
+    """MGTransferGlobalCoarseningTools::create_geometric_coarsening_sequence: coarsest first."""
+    seq = [fine]
+    while seq[-1].n_cells > 1:
+        seq.append(seq[-1].coarsen())
+    return seq[::-1]
+
+
+def create_polynomial_coarsening_sequence(degree: int):
+    """...::create_polynomial_coarsening_sequence(degree, bisect): e.g. 4 -> [1, 2, 4]."""
+    seq = [degree]
+    while seq[-1] > 1:
+        seq.append(max(seq[-1] // 2, 1))
+    return seq[::-1]
+
+
+class DoFs:
+    def __init__(self, tria: Triangulation, degree: int, max_brick: int = 0):
+        self.tria = tria
+        self._h = C.c_void_p()
+        _chk(_lib.mgamd_dofs_create(tria._h, degree, max_brick, C.byref(self._h)))
+        self.info = DofsInfo()
+        _chk(_lib.mgamd_dofs_info(self._h, C.byref(self.info)))
+        self.degree = degree
+        self.n_dofs = self.info.n_dofs
+
+    def keys(self):
+        k = np.zeros((self.n_dofs, 5), np.int32)
+        _chk(_lib.mgamd_dofs_get_keys(self._h, _ptr(k)))
+        return k
+
+    def cell_dofs(self):
+        out = np.zeros((self.info.n_cells, (self.degree + 1) ** 3), np.uint32)
+        _chk(_lib.mgamd_dofs_get_cell_dofs(self._h, _ptr(out)))
+        return out
+
+    def rhs_constant(self):
+        b = np.zeros(self.n_dofs)
+        _chk(_lib.mgamd_dofs_rhs_constant(self._h, _ptr(b)))
+        return b
+
+    def groups(self):
+        return [(self.info.group_B[g], self.info.group_slots[g]) for g in range(self.info.n_groups)]
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.mgamd_dofs_destroy(self._h)
+            self._h = None
+
+
+def transfer_tables(fine: DoFs, coarse: DoFs):
+    """raw two-level tables for the CPU oracle: list of (kind, nf, coarse_idx, coarse_mask, fine_idx)."""
+    npatch = (C.c_uint64 * 3)()
+    nf = (C.c_uint32 * 3)()
+    _chk(_lib.mgamd_transfer_tables_info(fine._h, coarse._h, npatch, nf))
+    out = []
+    nc3 = (coarse.degree + 1) ** 3
+    for kind in range(3):
+        n = npatch[kind]
+        ci = np.zeros((n, nc3), np.uint32)
+        cm = np.zeros(n, np.uint16)
+        fi = np.zeros((n, nf[kind] ** 3), np.uint32)
+        if n:
+            _chk(_lib.mgamd_transfer_tables_get(fine._h, coarse._h, kind, _ptr(ci), _ptr(cm), _ptr(fi)))
+        out.append((kind, int(nf[kind]), ci, cm, fi))
+    return out
+
+
+class Context:
+    def __init__(self, device: int = 0):
+        self._h = C.c_void_p()
+        _chk(_lib.mgamd_ctx_create(device, C.byref(self._h)))
+
+    def synchronize(self):
+        _chk(_lib.mgamd_ctx_synchronize(self._h))
+
+    def stream(self) -> int:
+        s = C.c_void_p()
+        _chk(_lib.mgamd_ctx_stream(self._h, C.byref(s)))
+        return s.value
+
+    def kernel_profile(self, enable: bool):
+        _chk(_lib.mgamd_ctx_kernel_profile(self._h, 1 if enable else 0))
+
+    def kernel_profile_read(self):
+        ms, n, b = C.c_double(), C.c_uint64(), C.c_double()
+        _chk(_lib.mgamd_ctx_kernel_profile_read(self._h, C.byref(ms), C.byref(n), C.byref(b)))
+        return ms.value, n.value, b.value
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.mgamd_ctx_destroy(self._h)
+            self._h = None
+
+
+class Vector:
+    """LinearAlgebra::distributed::Vector<Number>, device resident."""
+
+    def __init__(self, ctx: Context, n: int, number_type: int = F64, _handle=None):
+        self.ctx = ctx
+        self._h = C.c_void_p()
+        if _handle is not None:
+            self._h = _handle
+        else:
+            _chk(_lib.mgamd_vec_create(ctx._h, C.c_uint64(n), number_type, C.byref(self._h)))
+        sz = C.c_uint64()
+        _chk(_lib.mgamd_vec_size(self._h, C.byref(sz)))
+        self.n = sz.value
+
+    def from_host(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        assert a.size == self.n
+        _chk(_lib.mgamd_vec_from_host(self._h, _ptr(a)))
+        return self
+
+    def to_host(self):
+        a = np.zeros(self.n)
+        _chk(_lib.mgamd_vec_to_host(self._h, _ptr(a)))
+        return a
+
+    def set(self, value: float):
+        _chk(_lib.mgamd_vec_set(self._h, C.c_double(value)))
+
+    def copy_from(self, other: "Vector"):
+        _chk(_lib.mgamd_vec_copy(self._h, other._h))
+
+    def sadd(self, s: float, a: float, x: "Vector"):
+        _chk(_lib.mgamd_vec_sadd(self._h, C.c_double(s), C.c_double(a), x._h))
+
+    def dot(self, other: "Vector") -> float:
+        r = C.c_double()
+        _chk(_lib.mgamd_vec_dot(self._h, other._h, C.byref(r)))
+        return r.value
+
+    def l2_norm(self) -> float:
+        r = C.c_double()
+        _chk(_lib.mgamd_vec_norm2(self._h, C.byref(r)))
+        return r.value
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.mgamd_vec_destroy(self._h)
+            self._h = None
+
+
+class Operator:
+    """Operator<3,1,Number> (ref:include/operator.h:11-557)."""
+
+    def __init__(self, ctx: Context, dofs: DoFs, number_type: int = F64):
+        self.ctx, self.dofs, self.number_type = ctx, dofs, number_type
+        self._h = C.c_void_p()
+        _chk(_lib.mgamd_level_op_create(ctx._h, dofs._h, number_type, C.byref(self._h)))
+
+    def m(self) -> int:
+        n = C.c_uint64()
+        _chk(_lib.mgamd_level_op_m(self._h, C.byref(n)))
+        return n.value
+
+    def initialize_dof_vector(self) -> Vector:
+        h = C.c_void_p()
+        _chk(_lib.mgamd_level_op_init_vector(self._h, C.byref(h)))
+        return Vector(self.ctx, 0, _handle=h)
+
+    def vmult(self, dst: Vector, src: Vector):
+        _chk(_lib.mgamd_level_op_vmult(self._h, dst._h, src._h))
+
+    def compute_inverse_diagonal(self, diagonal: Vector):
+        _chk(_lib.mgamd_level_op_inverse_diagonal(self._h, diagonal._h))
+
+    def rhs(self, b: Vector):
+        _chk(_lib.mgamd_level_op_rhs(self._h, b._h))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.mgamd_level_op_destroy(self._h)
+            self._h = None
+
+
+class PreconditionChebyshev:
+    def __init__(self, op: Operator, degree=3, smoothing_range=20.0, eig_cg_n_iterations=20):
+        self.op = op
+        self._h = C.c_void_p()
+        _chk(_lib.mgamd_cheb_create(op._h, degree, C.c_double(smoothing_range), eig_cg_n_iterations, C.byref(self._h)))
+
+    def vmult(self, dst: Vector, src: Vector):
+        _chk(_lib.mgamd_cheb_vmult(self._h, dst._h, src._h))
+
+    def step(self, dst: Vector, src: Vector):
+        _chk(_lib.mgamd_cheb_step(self._h, dst._h, src._h))
+
+    def eigenvalue_estimates(self):
+        lo, hi = C.c_double(), C.c_double()
+        _chk(_lib.mgamd_cheb_get_eigen_estimates(self._h, C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.mgamd_cheb_destroy(self._h)
+            self._h = None
+
+
+class MGTwoLevelTransfer:
+    def __init__(self, fine: Operator, coarse: Operator):
+        self.fine, self.coarse = fine, coarse
+        self._h = C.c_void_p()
+        _chk(_lib.mgamd_transfer2_create(fine._h, coarse._h, C.byref(self._h)))
+
+    def prolongate_and_add(self, dst_fine: Vector, src_coarse: Vector):
+        _chk(_lib.mgamd_transfer2_prolongate_and_add(self._h, dst_fine._h, src_coarse._h))
+
+    def restrict_and_add(self, dst_coarse: Vector, src_fine: Vector):
+        _chk(_lib.mgamd_transfer2_restrict_and_add(self._h, dst_coarse._h, src_fine._h))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.mgamd_transfer2_destroy(self._h)
+            self._h = None
+
+
+STAGE_NAMES = ["pre_smoother_step", "residual_step", "restriction", "coarse_solve", "prolongation", "edge_prolongation",
+               "post_smoother_step", "transfer_to_mg", "transfer_to_global"]
+_STAGE_CB = C.CFUNCTYPE(None, C.c_int, C.c_int, C.c_uint, C.c_void_p)
+
+
+class PreconditionMG:
+    """Multigrid<Vector> + PreconditionMG over MGTransferGlobalCoarsening."""
+
+    def __init__(self, ctx: Context, levels, transfers, smoothers, coarse_solver="direct"):
+        self.ctx, self.levels, self.transfers, self.smoothers = ctx, levels, transfers, smoothers
+        n = len(levels)
+        L = (C.c_void_p * n)(*[l._h for l in levels])
+        T = (C.c_void_p * n)(*[(t._h if t is not None else None) for t in transfers])
+        S = (C.c_void_p * n)(*[(s._h if s is not None else None) for s in smoothers])
+        self._h = C.c_void_p()
+        _chk(_lib.mgamd_mg_create(ctx._h, n, L, T, S, coarse_solver.encode(), C.byref(self._h)))
+        self._cb = None
+
+    def vmult(self, z: Vector, r: Vector):
+        _chk(_lib.mgamd_mg_vcycle(self._h, z._h, r._h))
+
+    def connect_stages(self, fn):
+        """fn(stage:int, start:bool, level:int) or None; see STAGE_NAMES."""
+        if fn is None:
+            self._cb = None
+            _chk(_lib.mgamd_mg_set_stage_callback(self._h, None, None))
+            return
+        self._cb = _STAGE_CB(lambda s, st, lv, u: fn(s, bool(st), lv))
+        _chk(_lib.mgamd_mg_set_stage_callback(self._h, self._cb, None))
+
+    def time_vcycles(self, z: Vector, r: Vector, n: int, use_graph: bool = True) -> float:
+        ms = C.c_double()
+        _chk(_lib.mgamd_mg_time_vcycles(self._h, z._h, r._h, n, 1 if use_graph else 0, C.byref(ms)))
+        return ms.value
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.mgamd_mg_destroy(self._h)
+            self._h = None
+
+
+def solve_cg(A: Operator, preconditioner, x: Vector, b: Vector, reltol=1e-4, abstol=1e-20, maxiter=10000):
+    """SolverCG<Vector>(ReductionControl(maxiter, abstol, reltol)).solve(A, x, b, preconditioner) from x = 0."""
+    it, res = C.c_uint(), C.c_double()
+    ph = preconditioner._h if preconditioner is not None else None
+    _chk(_lib.mgamd_solve_cg(A._h, ph, x._h, b._h, C.c_double(reltol), C.c_double(abstol), maxiter, C.byref(it), C.byref(res)))
+    return it.value, res.value
+
+
+class Hierarchy:
+    """What solve_with_global_coarsening builds (ref:multigrid_throughput.cc:1443-1666)."""
+
+    def __init__(self, ctx: Context, geometry="quadrant", n_ref_global=3, degree=1, mg_type="HMG-global", n_ref_local=0,
+                 smoother_degree=3, smoothing_range=20.0, eig_cg_n_iterations=20, coarse_solver="amg", number_type=F64,
+                 max_brick=0):
+        self.ctx = ctx
+        fine = Triangulation(geometry, n_ref_global, n_ref_local)
+        if mg_type == "HMG-global":
+            self.trias = create_geometric_coarsening_sequence(fine)
+            self.degrees = [degree] * len(self.trias)
+        elif mg_type == "PMG":
+            self.degrees = create_polynomial_coarsening_sequence(degree)
+            self.trias = [fine] * len(self.degrees)
+        else:
+            raise MgamdError(f"Type '{mg_type}' not implemented")
+        self.dofs = [DoFs(t, p, max_brick) for t, p in zip(self.trias, self.degrees)]
+        self.operators = [Operator(ctx, d, number_type) for d in self.dofs]
+        self.transfers = [None] + [MGTwoLevelTransfer(self.operators[l], self.operators[l - 1]) for l in range(1, len(self.dofs))]
+        self.smoothers = [PreconditionChebyshev(op, smoother_degree, smoothing_range, eig_cg_n_iterations) for op in self.operators]
+        self.mg = PreconditionMG(ctx, self.operators, self.transfers, self.smoothers, coarse_solver)
+        self.fine_operator = self.operators[-1] if number_type == F64 else Operator(ctx, self.dofs[-1], F64)
+        self.n_dofs = self.dofs[-1].n_dofs

@@ -1,0 +1,818 @@
+// HIP kernels for gfx950 (CDNA4, wave64).  Hand-written for MI355X: no hipify, no dual paths.
+//
+// K1  lattice_apply_kernel   the level operator (ref:include/operator.h:152-183,461-472) on one SLOT
+//                            (brick of B^3 cells or single cell) per work-item group: node lattice
+//                            of N = p*B+1 points per direction staged in LDS, three 1D sweeps with
+//                            one thread per lattice line and the line in registers, epilogue fused
+//                            (vmult / residual / Chebyshev update) for slot-interior DoFs, partial
+//                            sums of shell DoFs atomically added to the small 'tail' accumulator.
+// K2  tail_kernel            same epilogue for the tail + constrained DoFs (identity rows).
+// K3  lattice_diag_kernel    diagonal of C^T K C (ref:include/operator.h:228-242).
+// K4  prolongate/restrict    MGTwoLevelTransfer embeddings (ref:multigrid_throughput.cc:1600-1604).
+// K5  vector kernels         set/copy/axpy/sadd/scaled pointwise product/dot.
+// K6  dense_matvec_kernel    coarse-grid direct solve (precomputed inverse).
+//
+// Because every cell is a cube (ref:include/grid_generator.h, MappingQ1) the brick operator is
+//   A_brick = h (K (x) M (x) M + M (x) K (x) M + M (x) M (x) K)
+// with 1D matrices assembled over the B cells of a lattice line; each 1D product is evaluated
+// cell by cell with the dense (p+1)^2 reference matrices held in SGPRs (kernel arguments).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mgamd
+{
+  constexpr uint32_t DEV_INVALID = 0xFFFFFFFFu;
+
+  template <int P>
+  struct Mats
+  {
+    double M[(P + 1) * (P + 1)];
+    double K[(P + 1) * (P + 1)];
+    double I0[(P + 1) * (P + 1)];
+    double I1[(P + 1) * (P + 1)];
+  };
+
+  template <int P, int B>
+  struct Geo
+  {
+    static constexpr int N       = P * B + 1;
+    static constexpr int N3      = N * N * N;
+    static constexpr int NI      = N - 2;
+    static constexpr int N_INT   = NI > 0 ? NI * NI * NI : 0;
+    static constexpr int N_SHELL = N3 - N_INT;
+    static constexpr int LINES   = N * N;
+    static constexpr int SPW     = LINES >= 256 ? 1 : 256 / LINES;
+    static constexpr int BLOCK   = ((SPW * LINES + 63) / 64) * 64;
+  };
+
+  struct SlotGroupDev
+  {
+    const uint32_t *interior_base;
+    const uint32_t *shell_idx;
+    const uint16_t *mask;
+    const double   *h;
+    const uint16_t *shell_pos;
+    uint32_t        n_slots;
+  };
+
+  enum ApplyMode
+  {
+    MODE_VMULT    = 0, // out = A x
+    MODE_RESIDUAL = 1, // out = b - A x
+    MODE_CHEB     = 2, // out = x + f1 (x - xold) + f2 dinv (b - A x)      (xold == nullptr: xold = 0)
+    MODE_INVDIAG  = 3  // out = |d| > 1e-10 ? 1/d : 1                       (d delivered as 'A x')
+  };
+
+  template <typename T>
+  struct Epilogue
+  {
+    T       *out;
+    const T *x; // operator input (src)
+    const T *xold;
+    const T *b;
+    const T *dinv;
+    T        f1, f2;
+  };
+
+  template <typename T, int MODE>
+  __device__ __forceinline__ void
+  apply_epilogue(const Epilogue<T> &e, uint32_t gi, T Ax)
+  {
+    if (MODE == MODE_VMULT)
+      e.out[gi] = Ax;
+    else if (MODE == MODE_RESIDUAL)
+      e.out[gi] = e.b[gi] - Ax;
+    else if (MODE == MODE_CHEB)
+      {
+        const T xv = e.x[gi];
+        const T xo = e.xold ? e.xold[gi] : T(0);
+        e.out[gi]  = xv + e.f1 * (xv - xo) + e.f2 * e.dinv[gi] * (e.b[gi] - Ax);
+      }
+    else
+      e.out[gi] = (fabs((double)Ax) > 1.0e-10) ? T(1) / Ax : T(1);
+  }
+
+  __device__ __forceinline__ void
+  atomic_add(double *p, double v)
+  {
+    unsafeAtomicAdd(p, v);
+  }
+  __device__ __forceinline__ void
+  atomic_add(float *p, float v)
+  {
+    unsafeAtomicAdd(p, v);
+  }
+
+  // out[0..N) = (1D matrix assembled from B copies of the (P+1)^2 cell matrix Mc) * in
+  template <typename T, int P, int B>
+  __device__ __forceinline__ void
+  line_mult(const double *__restrict__ Mc, const T (&in)[P * B + 1], T (&out)[P * B + 1])
+  {
+#pragma unroll
+    for (int i = 0; i < P * B + 1; ++i)
+      out[i] = T(0);
+#pragma unroll
+    for (int c = 0; c < B; ++c)
+#pragma unroll
+      for (int a = 0; a <= P; ++a)
+#pragma unroll
+        for (int b = 0; b <= P; ++b)
+          out[c * P + a] += T(Mc[a * (P + 1) + b]) * in[c * P + b];
+  }
+
+  // The three sweeps.  Thread (sl, u, v) owns lattice line (u,v) of slot sl in every sweep.
+  // bufA holds the input and receives the result; bufB is scratch.  Ends with a barrier.
+  template <typename T, int P, int B>
+  __device__ __forceinline__ void
+  lattice_sweeps(T *__restrict__ bufA, T *__restrict__ bufB, const Mats<P> &m, int sl, int u, int v, bool act, T h)
+  {
+    constexpr int N  = Geo<P, B>::N;
+    constexpr int N3 = Geo<P, B>::N3;
+    T             r0[N], r1[N], r2[N];
+    // z sweep: thread = (x=u, y=v)
+    if (act)
+      {
+        const int base = sl * N3 + v * N + u;
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          r0[i] = bufA[base + i * N * N];
+        line_mult<T, P, B>(m.M, r0, r1);
+        line_mult<T, P, B>(m.K, r0, r2);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          {
+            bufA[base + i * N * N] = r1[i];
+            bufB[base + i * N * N] = r2[i];
+          }
+      }
+    __syncthreads();
+    // y sweep: thread = (x=u, z=v):  c = My a ; g = Ky a + My b
+    if (act)
+      {
+        const int base = sl * N3 + v * N * N + u;
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          r0[i] = bufA[base + i * N];
+        line_mult<T, P, B>(m.M, r0, r1);
+        line_mult<T, P, B>(m.K, r0, r2);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          {
+            bufA[base + i * N] = r1[i];
+            r0[i]              = bufB[base + i * N];
+          }
+        line_mult<T, P, B>(m.M, r0, r1);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          bufB[base + i * N] = r1[i] + r2[i];
+      }
+    __syncthreads();
+    // x sweep: thread = (y=u, z=v): out = h (Kx c + Mx g)
+    if (act)
+      {
+        const int base = sl * N3 + (v * N + u) * N;
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          r0[i] = bufA[base + i];
+        line_mult<T, P, B>(m.K, r0, r1);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          r0[i] = bufB[base + i];
+        line_mult<T, P, B>(m.M, r0, r2);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          bufA[base + i] = h * (r1[i] + r2[i]);
+      }
+    __syncthreads();
+  }
+
+  // In-cell hanging-node interpolation (transpose = false, before the sweeps) or its transpose
+  // (after), for single-cell slots (N = P+1).  One thread per line; only lines on hanging
+  // faces/edges do work.  Ends with a barrier.
+  template <typename T, int P>
+  __device__ __forceinline__ void
+  hanging_passes(T *__restrict__ buf, const Mats<P> &m, int sl, int u, int v, bool act, uint32_t mask, bool transpose)
+  {
+    constexpr int N  = P + 1;
+    constexpr int N3 = N * N * N;
+    const int     cx = mask & 1, cy = (mask >> 1) & 1, cz = (mask >> 2) & 1;
+    const bool    fx = (mask >> 3) & 1, fy = (mask >> 4) & 1, fz = (mask >> 5) & 1;
+    const bool    ex = (mask >> 6) & 1, ey = (mask >> 7) & 1, ez = (mask >> 8) & 1;
+#pragma unroll
+    for (int dd = 0; dd < 3; ++dd)
+      {
+        const int d = transpose ? 2 - dd : dd;
+        bool      on;
+        int       base, stride, c;
+        if (d == 0)
+          { // x lines, (u,v) = (y,z)
+            const bool ou = u == cy * P, ov = v == cz * P;
+            on            = (fy && ou) || (fz && ov) || (ex && ou && ov);
+            base          = sl * N3 + (v * N + u) * N;
+            stride        = 1;
+            c             = cx;
+          }
+        else if (d == 1)
+          { // y lines, (u,v) = (x,z)
+            const bool ou = u == cx * P, ov = v == cz * P;
+            on            = (fx && ou) || (fz && ov) || (ey && ou && ov);
+            base          = sl * N3 + v * N * N + u;
+            stride        = N;
+            c             = cy;
+          }
+        else
+          { // z lines, (u,v) = (x,y)
+            const bool ou = u == cx * P, ov = v == cy * P;
+            on            = (fx && ou) || (fy && ov) || (ez && ou && ov);
+            base          = sl * N3 + v * N + u;
+            stride        = N * N;
+            c             = cz;
+          }
+        if (act && on && (mask >> 3))
+          {
+            T in[N], out[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              in[i] = buf[base + i * stride];
+#pragma unroll
+            for (int a = 0; a < N; ++a)
+              {
+                T s = T(0);
+#pragma unroll
+                for (int b = 0; b < N; ++b)
+                  {
+                    const int    k = transpose ? b * N + a : a * N + b;
+                    const double w = c ? m.I1[k] : m.I0[k];
+                    s += T(w) * in[b];
+                  }
+                out[a] = s;
+              }
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              buf[base + i * stride] = out[i];
+          }
+        __syncthreads();
+      }
+  }
+
+  template <typename T, int P>
+  struct ApplyArgs
+  {
+    SlotGroupDev g;
+    Mats<P>      m;
+    const T     *src;
+    T           *tail_acc; // [n_tail] accumulators of shell partial sums
+    uint32_t     n_interior;
+    Epilogue<T>  epi;
+  };
+
+  // gather the slots of this workgroup into LDS
+  template <typename T, int P, int B>
+  __device__ __forceinline__ void
+  lattice_gather(T *__restrict__ bufA, const SlotGroupDev &g, const T *__restrict__ src, int slot0, int nslots, int tid)
+  {
+    using G = Geo<P, B>;
+    if (G::N_INT > 0)
+      for (int idx = tid; idx < nslots * G::N_INT; idx += G::BLOCK)
+        {
+          const int sl = idx / (G::N_INT > 0 ? G::N_INT : 1), i = idx % (G::N_INT > 0 ? G::N_INT : 1);
+          const int x = i % (G::NI > 0 ? G::NI : 1), y = (i / (G::NI > 0 ? G::NI : 1)) % (G::NI > 0 ? G::NI : 1),
+                    z = i / (G::NI > 0 ? G::NI * G::NI : 1);
+          bufA[sl * G::N3 + ((z + 1) * G::N + (y + 1)) * G::N + x + 1] = src[g.interior_base[slot0 + sl] + i];
+        }
+    for (int idx = tid; idx < nslots * G::N_SHELL; idx += G::BLOCK)
+      {
+        const int      sl = idx / G::N_SHELL, s = idx % G::N_SHELL;
+        const uint32_t gi = g.shell_idx[(size_t)(slot0 + sl) * G::N_SHELL + s];
+        bufA[sl * G::N3 + g.shell_pos[s]] = gi != DEV_INVALID ? src[gi] : T(0);
+      }
+  }
+
+  template <typename T, int P, int B, int MODE>
+  __global__ void
+  __launch_bounds__((Geo<P, B>::BLOCK)) lattice_apply_kernel(const ApplyArgs<T, P> args)
+  {
+    using G = Geo<P, B>;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    T *bufA = reinterpret_cast<T *>(smem_raw);
+    T *bufB = bufA + G::SPW * G::N3;
+
+    const int tid    = threadIdx.x;
+    const int slot0  = blockIdx.x * G::SPW;
+    const int nslots = min((int)G::SPW, (int)args.g.n_slots - slot0);
+    const int sl     = tid / G::LINES;
+    const int ln     = tid % G::LINES;
+    const int u = ln % G::N, v = ln / G::N;
+    const bool act = tid < G::SPW * G::LINES && sl < nslots;
+
+    lattice_gather<T, P, B>(bufA, args.g, args.src, slot0, nslots, tid);
+    __syncthreads();
+
+    uint32_t mask = 0;
+    T        h    = T(0);
+    if (act)
+      {
+        h = T(args.g.h[slot0 + sl]);
+        if (B == 1)
+          mask = args.g.mask[slot0 + sl];
+      }
+    bool any_hanging = false;
+    if (B == 1)
+      {
+        any_hanging = __syncthreads_or((int)(mask >> 3)) != 0;
+        if (any_hanging)
+          hanging_passes<T, P>(bufA, args.m, sl, u, v, act, mask, false);
+      }
+
+    lattice_sweeps<T, P, B>(bufA, bufB, args.m, sl, u, v, act, h);
+
+    if (B == 1 && any_hanging)
+      hanging_passes<T, P>(bufA, args.m, sl, u, v, act, mask, true);
+
+    // interior DoFs are complete: fused epilogue, contiguous stores
+    if (G::N_INT > 0)
+      for (int idx = tid; idx < nslots * G::N_INT; idx += G::BLOCK)
+        {
+          const int sl2 = idx / (G::N_INT > 0 ? G::N_INT : 1), i = idx % (G::N_INT > 0 ? G::N_INT : 1);
+          const int x = i % (G::NI > 0 ? G::NI : 1), y = (i / (G::NI > 0 ? G::NI : 1)) % (G::NI > 0 ? G::NI : 1),
+                    z = i / (G::NI > 0 ? G::NI * G::NI : 1);
+          const T Ax = bufA[sl2 * G::N3 + ((z + 1) * G::N + (y + 1)) * G::N + x + 1];
+          apply_epilogue<T, MODE>(args.epi, args.g.interior_base[slot0 + sl2] + i, Ax);
+        }
+    // shell DoFs: partial sums into the tail accumulator
+    for (int idx = tid; idx < nslots * G::N_SHELL; idx += G::BLOCK)
+      {
+        const int      sl2 = idx / G::N_SHELL, s = idx % G::N_SHELL;
+        const uint32_t gi  = args.g.shell_idx[(size_t)(slot0 + sl2) * G::N_SHELL + s];
+        if (gi != DEV_INVALID)
+          atomic_add(&args.tail_acc[gi - args.n_interior], bufA[sl2 * G::N3 + args.g.shell_pos[s]]);
+      }
+  }
+
+  // Diagonal of C^T K C.  Slots without hanging nodes: closed tensor form; single cells with hanging
+  // faces/edges: one unit vector per local node through interpolation, sweeps and transpose.
+  template <typename T, int P, int B>
+  __global__ void
+  __launch_bounds__((Geo<P, B>::BLOCK)) lattice_diag_kernel(const ApplyArgs<T, P> args)
+  {
+    using G = Geo<P, B>;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    T *bufA = reinterpret_cast<T *>(smem_raw);
+    T *bufB = bufA + G::SPW * G::N3;
+    T *bufD = bufB + G::SPW * G::N3;
+
+    const int tid    = threadIdx.x;
+    const int slot0  = blockIdx.x * G::SPW;
+    const int nslots = min((int)G::SPW, (int)args.g.n_slots - slot0);
+    const int sl     = tid / G::LINES;
+    const int ln     = tid % G::LINES;
+    const int u = ln % G::N, v = ln / G::N;
+    const bool act = tid < G::SPW * G::LINES && sl < nslots;
+
+    uint32_t mask = 0;
+    T        h    = T(0);
+    if (act)
+      {
+        h = T(args.g.h[slot0 + sl]);
+        if (B == 1)
+          mask = args.g.mask[slot0 + sl];
+      }
+    // closed form: thread (u,v) = (x,y) fills its z column
+    if (act)
+      {
+        T dM[G::N], dK[G::N];
+#pragma unroll
+        for (int i = 0; i < G::N; ++i)
+          dM[i] = dK[i] = T(0);
+#pragma unroll
+        for (int c = 0; c < B; ++c)
+#pragma unroll
+          for (int a = 0; a <= P; ++a)
+            {
+              dM[c * P + a] += T(args.m.M[a * (P + 1) + a]);
+              dK[c * P + a] += T(args.m.K[a * (P + 1) + a]);
+            }
+        T mx = T(0), kx = T(0), my = T(0), ky = T(0);
+#pragma unroll
+        for (int i = 0; i < G::N; ++i)
+          {
+            if (i == u)
+              {
+                mx = dM[i];
+                kx = dK[i];
+              }
+            if (i == v)
+              {
+                my = dM[i];
+                ky = dK[i];
+              }
+          }
+#pragma unroll
+        for (int i = 0; i < G::N; ++i)
+          bufD[sl * G::N3 + (i * G::N + v) * G::N + u] = h * (kx * my * dM[i] + mx * ky * dM[i] + mx * my * dK[i]);
+      }
+    __syncthreads();
+    if (B == 1)
+      {
+        const bool any_hanging = __syncthreads_or((int)(mask >> 3)) != 0;
+        if (any_hanging)
+          for (int j = 0; j < G::N3; ++j)
+            {
+              // e_j on every slot of this workgroup
+              for (int idx = tid; idx < G::SPW * G::N3; idx += G::BLOCK)
+                bufA[idx] = (idx % G::N3) == j ? T(1) : T(0);
+              __syncthreads();
+              hanging_passes<T, P>(bufA, args.m, sl, u, v, act, mask, false);
+              lattice_sweeps<T, P, B>(bufA, bufB, args.m, sl, u, v, act, h);
+              hanging_passes<T, P>(bufA, args.m, sl, u, v, act, mask, true);
+              if (act && ln == 0 && (mask >> 3))
+                bufD[sl * G::N3 + j] = bufA[sl * G::N3 + j];
+              __syncthreads();
+            }
+      }
+    if (G::N_INT > 0)
+      for (int idx = tid; idx < nslots * G::N_INT; idx += G::BLOCK)
+        {
+          const int sl2 = idx / (G::N_INT > 0 ? G::N_INT : 1), i = idx % (G::N_INT > 0 ? G::N_INT : 1);
+          const int x = i % (G::NI > 0 ? G::NI : 1), y = (i / (G::NI > 0 ? G::NI : 1)) % (G::NI > 0 ? G::NI : 1),
+                    z = i / (G::NI > 0 ? G::NI * G::NI : 1);
+          const T d = bufD[sl2 * G::N3 + ((z + 1) * G::N + (y + 1)) * G::N + x + 1];
+          apply_epilogue<T, MODE_INVDIAG>(args.epi, args.g.interior_base[slot0 + sl2] + i, d);
+        }
+    for (int idx = tid; idx < nslots * G::N_SHELL; idx += G::BLOCK)
+      {
+        const int      sl2 = idx / G::N_SHELL, s = idx % G::N_SHELL;
+        const uint32_t gi  = args.g.shell_idx[(size_t)(slot0 + sl2) * G::N_SHELL + s];
+        if (gi != DEV_INVALID)
+          atomic_add(&args.tail_acc[gi - args.n_interior], bufD[sl2 * G::N3 + args.g.shell_pos[s]]);
+      }
+  }
+
+  // Epilogue for the tail (accumulated shell sums) and the constrained DoFs (identity rows:
+  // ref:include/operator.h:170-172); re-zeroes the accumulator for the next application.
+  template <typename T, int MODE>
+  __global__ void
+  __launch_bounds__(256) tail_kernel(T *__restrict__ tail_acc, uint32_t n_interior, uint32_t n_tail, uint32_t n_rest, Epilogue<T> epi)
+  {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_tail + n_rest; i += stride)
+      {
+        const uint32_t gi = n_interior + i;
+        T              Ax;
+        if (i < n_tail)
+          {
+            Ax          = tail_acc[i];
+            tail_acc[i] = T(0);
+          }
+        else
+          Ax = (MODE == MODE_INVDIAG) ? T(0) : epi.x[gi];
+        apply_epilogue<T, MODE>(epi, gi, Ax);
+      }
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // Two-level transfer.  One patch (coarse cell) per thread group; fine patch lattice NF^3.
+  // ------------------------------------------------------------------------------------------
+  template <int PC, int NF>
+  struct TransferGeo
+  {
+    static constexpr int NC    = PC + 1;
+    static constexpr int NC3   = NC * NC * NC;
+    static constexpr int NF3   = NF * NF * NF;
+    static constexpr int LINES = NF * NF;
+    static constexpr int SPW   = LINES >= 256 ? 1 : 256 / LINES;
+    static constexpr int BLOCK = ((SPW * LINES + 63) / 64) * 64;
+  };
+
+  template <typename T, int PC, int NF>
+  struct TransferArgs
+  {
+    const uint32_t *coarse_idx;  // [n_patches][NC3]
+    const uint16_t *coarse_mask; // [n_patches]
+    const uint32_t *fine_idx;    // [n_patches][NF3]
+    uint32_t        n_patches;
+    Mats<PC>        m;              // only I0/I1 are used (coarse hanging nodes)
+    double          E[NF * (PC + 1)]; // 1D embedding, rows = fine nodes
+    const T        *src;
+    T              *dst;
+  };
+
+  // x_f[owned fine DoFs] += E (x) E (x) E  (C_cell x_c)
+  template <typename T, int PC, int NF, bool IDENTITY>
+  __global__ void
+  __launch_bounds__((TransferGeo<PC, NF>::BLOCK)) prolongate_kernel(const TransferArgs<T, PC, NF> args)
+  {
+    using G = TransferGeo<PC, NF>;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    T *bufA = reinterpret_cast<T *>(smem_raw); // SPW * NF3
+    T *bufB = bufA + G::SPW * G::NF3;
+
+    const int tid    = threadIdx.x;
+    const int p0     = blockIdx.x * G::SPW;
+    const int np     = min((int)G::SPW, (int)args.n_patches - p0);
+    const int sl     = tid / G::LINES;
+    const int ln     = tid % G::LINES;
+    const int u = ln % NF, v = ln / NF;
+    const bool act = tid < G::SPW * G::LINES && sl < np;
+
+    // gather coarse values into bufB (stride NC3 per patch)
+    for (int idx = tid; idx < np * G::NC3; idx += G::BLOCK)
+      {
+        const int      s  = idx / G::NC3, i = idx % G::NC3;
+        const uint32_t gi = args.coarse_idx[(size_t)(p0 + s) * G::NC3 + i];
+        bufB[s * G::NF3 + i] = gi != DEV_INVALID ? args.src[gi] : T(0);
+      }
+    __syncthreads();
+    uint32_t mask = 0;
+    if (act)
+      mask = args.coarse_mask[p0 + sl];
+    const bool any_hanging = __syncthreads_or((int)(mask >> 3)) != 0;
+    if (any_hanging)
+      {
+        // hanging_passes expects patch stride NC3: run it on a view with that stride
+        // (bufB patches are NF3 apart, so handle the offset by hand)
+        T        *view = bufB + sl * (G::NF3 - G::NC3);
+        const bool la  = act && u < G::NC && v < G::NC;
+        hanging_passes<T, PC>(view, args.m, sl, u, v, la, la ? mask : 0u, false);
+      }
+    if (IDENTITY)
+      {
+        for (int idx = tid; idx < np * G::NF3; idx += G::BLOCK)
+          {
+            const int      s  = idx / G::NF3, i = idx % G::NF3;
+            const uint32_t gi = args.fine_idx[(size_t)(p0 + s) * G::NF3 + i];
+            if (gi != DEV_INVALID)
+              args.dst[gi] += bufB[s * G::NF3 + i];
+          }
+        return;
+      }
+    // x: (NC,NC,NC) -> (NC,NC,NF); thread (u,v) = (y,z) < NC
+    if (act && u < G::NC && v < G::NC)
+      {
+        T in[G::NC];
+#pragma unroll
+        for (int b = 0; b < G::NC; ++b)
+          in[b] = bufB[sl * G::NF3 + (v * G::NC + u) * G::NC + b];
+#pragma unroll
+        for (int a = 0; a < NF; ++a)
+          {
+            T s = T(0);
+#pragma unroll
+            for (int b = 0; b < G::NC; ++b)
+              s += T(args.E[a * G::NC + b]) * in[b];
+            bufA[sl * G::NF3 + (v * G::NC + u) * NF + a] = s;
+          }
+      }
+    __syncthreads();
+    // y: (NC z, NC y, NF x) -> (NC z, NF y, NF x); thread (u,v) = (x < NF, z < NC)
+    if (act && v < G::NC)
+      {
+        T in[G::NC];
+#pragma unroll
+        for (int b = 0; b < G::NC; ++b)
+          in[b] = bufA[sl * G::NF3 + (v * G::NC + b) * NF + u];
+#pragma unroll
+        for (int a = 0; a < NF; ++a)
+          {
+            T s = T(0);
+#pragma unroll
+            for (int b = 0; b < G::NC; ++b)
+              s += T(args.E[a * G::NC + b]) * in[b];
+            bufB[sl * G::NF3 + (v * NF + a) * NF + u] = s;
+          }
+      }
+    __syncthreads();
+    // z: (NC z, NF, NF) -> (NF, NF, NF); thread (u,v) = (x,y) < NF; result straight to global
+    if (act)
+      {
+        T in[G::NC];
+#pragma unroll
+        for (int b = 0; b < G::NC; ++b)
+          in[b] = bufB[sl * G::NF3 + (b * NF + v) * NF + u];
+#pragma unroll
+        for (int a = 0; a < NF; ++a)
+          {
+            T s = T(0);
+#pragma unroll
+            for (int b = 0; b < G::NC; ++b)
+              s += T(args.E[a * G::NC + b]) * in[b];
+            bufA[sl * G::NF3 + (a * NF + v) * NF + u] = s;
+          }
+      }
+    __syncthreads();
+    for (int idx = tid; idx < np * G::NF3; idx += G::BLOCK)
+      {
+        const int      s  = idx / G::NF3, i = idx % G::NF3;
+        const uint32_t gi = args.fine_idx[(size_t)(p0 + s) * G::NF3 + i];
+        if (gi != DEV_INVALID)
+          args.dst[gi] += bufA[s * G::NF3 + i];
+      }
+  }
+
+  // d_c += C_cell^T (E (x) E (x) E)^T r_f[owned fine DoFs]
+  template <typename T, int PC, int NF, bool IDENTITY>
+  __global__ void
+  __launch_bounds__((TransferGeo<PC, NF>::BLOCK)) restrict_kernel(const TransferArgs<T, PC, NF> args)
+  {
+    using G = TransferGeo<PC, NF>;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    T *bufA = reinterpret_cast<T *>(smem_raw);
+    T *bufB = bufA + G::SPW * G::NF3;
+
+    const int tid    = threadIdx.x;
+    const int p0     = blockIdx.x * G::SPW;
+    const int np     = min((int)G::SPW, (int)args.n_patches - p0);
+    const int sl     = tid / G::LINES;
+    const int ln     = tid % G::LINES;
+    const int u = ln % NF, v = ln / NF;
+    const bool act = tid < G::SPW * G::LINES && sl < np;
+
+    for (int idx = tid; idx < np * G::NF3; idx += G::BLOCK)
+      {
+        const int      s  = idx / G::NF3, i = idx % G::NF3;
+        const uint32_t gi = args.fine_idx[(size_t)(p0 + s) * G::NF3 + i];
+        bufA[s * G::NF3 + i] = gi != DEV_INVALID ? args.src[gi] : T(0);
+      }
+    __syncthreads();
+    if (!IDENTITY)
+      {
+        // z^T: (NF,NF,NF) -> (NC z, NF, NF); thread (x,y) < NF
+        if (act)
+          {
+            T in[NF];
+#pragma unroll
+            for (int a = 0; a < NF; ++a)
+              in[a] = bufA[sl * G::NF3 + (a * NF + v) * NF + u];
+#pragma unroll
+            for (int b = 0; b < G::NC; ++b)
+              {
+                T s = T(0);
+#pragma unroll
+                for (int a = 0; a < NF; ++a)
+                  s += T(args.E[a * G::NC + b]) * in[a];
+                bufB[sl * G::NF3 + (b * NF + v) * NF + u] = s;
+              }
+          }
+        __syncthreads();
+        // y^T: (NC z, NF y, NF x) -> (NC z, NC y, NF x); thread (x < NF, z < NC)
+        if (act && v < G::NC)
+          {
+            T in[NF];
+#pragma unroll
+            for (int a = 0; a < NF; ++a)
+              in[a] = bufB[sl * G::NF3 + (v * NF + a) * NF + u];
+#pragma unroll
+            for (int b = 0; b < G::NC; ++b)
+              {
+                T s = T(0);
+#pragma unroll
+                for (int a = 0; a < NF; ++a)
+                  s += T(args.E[a * G::NC + b]) * in[a];
+                bufA[sl * G::NF3 + (v * G::NC + b) * NF + u] = s;
+              }
+          }
+        __syncthreads();
+        // x^T: (NC, NC, NF x) -> (NC,NC,NC) compact with stride NC3 inside the patch's bufB region
+        if (act && u < G::NC && v < G::NC)
+          {
+            T in[NF];
+#pragma unroll
+            for (int a = 0; a < NF; ++a)
+              in[a] = bufA[sl * G::NF3 + (v * G::NC + u) * NF + a];
+#pragma unroll
+            for (int b = 0; b < G::NC; ++b)
+              {
+                T s = T(0);
+#pragma unroll
+                for (int a = 0; a < NF; ++a)
+                  s += T(args.E[a * G::NC + b]) * in[a];
+                bufB[sl * G::NF3 + (v * G::NC + u) * G::NC + b] = s;
+              }
+          }
+        __syncthreads();
+      }
+    T *res = IDENTITY ? bufA : bufB;
+    uint32_t mask = 0;
+    if (act)
+      mask = args.coarse_mask[p0 + sl];
+    const bool any_hanging = __syncthreads_or((int)(mask >> 3)) != 0;
+    if (any_hanging)
+      {
+        T         *view = res + sl * (G::NF3 - G::NC3);
+        const bool la   = act && u < G::NC && v < G::NC;
+        hanging_passes<T, PC>(view, args.m, sl, u, v, la, la ? mask : 0u, true);
+      }
+    for (int idx = tid; idx < np * G::NC3; idx += G::BLOCK)
+      {
+        const int      s  = idx / G::NC3, i = idx % G::NC3;
+        const uint32_t gi = args.coarse_idx[(size_t)(p0 + s) * G::NC3 + i];
+        if (gi != DEV_INVALID)
+          atomic_add(&args.dst[gi], res[s * G::NF3 + i]);
+      }
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // Vector kernels
+  // ------------------------------------------------------------------------------------------
+  template <typename T>
+  __global__ void
+  __launch_bounds__(256) vec_set_kernel(T *__restrict__ v, T value, size_t n)
+  {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+      v[i] = value;
+  }
+
+  template <typename TD, typename TS>
+  __global__ void
+  __launch_bounds__(256) vec_copy_kernel(TD *__restrict__ d, const TS *__restrict__ s, size_t n)
+  {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+      d[i] = (TD)s[i];
+  }
+
+  // y = s*y + a*x
+  template <typename T>
+  __global__ void
+  __launch_bounds__(256) vec_sadd_kernel(T *__restrict__ y, T s, T a, const T *__restrict__ x, size_t n)
+  {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+      y[i] = s * y[i] + a * x[i];
+  }
+
+  // y = a * d .* b      (Chebyshev zero-start first iterate: x1 = (1/theta) D^-1 b)
+  template <typename T>
+  __global__ void
+  __launch_bounds__(256) vec_scaled_product_kernel(T *__restrict__ y, T a, const T *__restrict__ d, const T *__restrict__ b, size_t n)
+  {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+      y[i] = a * d[i] * b[i];
+  }
+
+  __device__ __forceinline__ double
+  wave_reduce_sum(double v)
+  {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+      v += __shfl_down(v, off, 64);
+    return v;
+  }
+
+  // stage 1: per-block partial sums of x.y (double accumulation); stage 2 (grid 1): final sum
+  template <typename T>
+  __global__ void
+  __launch_bounds__(256) vec_dot_kernel(const T *__restrict__ x, const T *__restrict__ y, size_t n, double *__restrict__ partial)
+  {
+    __shared__ double wsum[4];
+    double            s      = 0.0;
+    const size_t      stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+      s += (double)x[i] * (double)y[i];
+    s = wave_reduce_sum(s);
+    if ((threadIdx.x & 63) == 0)
+      wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      partial[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  }
+
+  __global__ void
+  __launch_bounds__(256) vec_dot_final_kernel(const double *__restrict__ partial, int n, double *__restrict__ result)
+  {
+    __shared__ double wsum[4];
+    double            s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256)
+      s += partial[i];
+    s = wave_reduce_sum(s);
+    if ((threadIdx.x & 63) == 0)
+      wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      *result = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  }
+
+  // y = Minv x for the coarse-grid direct solve (Minv: n x n row-major, double)
+  template <typename T>
+  __global__ void
+  __launch_bounds__(256) dense_matvec_kernel(const double *__restrict__ Minv, const T *__restrict__ x, T *__restrict__ y, int n)
+  {
+    __shared__ double wsum[4];
+    for (int row = blockIdx.x; row < n; row += gridDim.x)
+      {
+        double s = 0.0;
+        for (int j = threadIdx.x; j < n; j += 256)
+          s += Minv[(size_t)row * n + j] * (double)x[j];
+        s = wave_reduce_sum(s);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0)
+          wsum[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0)
+          y[row] = (T)(wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+      }
+  }
+} // namespace mgamd

@@ -1,0 +1,1261 @@
+// Device runtime implementation (see runtime.hpp).  Compiled with hipcc --offload-arch=gfx950.
+#include "runtime.hpp"
+#include "kernels.hpp"
+
+#include <chrono>
+#include <cmath>
+
+namespace mgamd
+{
+  // ------------------------------------------------------------------------------------------
+  // Context
+  // ------------------------------------------------------------------------------------------
+  Ctx::Ctx(int dev)
+    : device(dev)
+  {
+    int        count = 0;
+    hipError_t e     = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+      throw NoDeviceError("no HIP device available: this library has no CPU fallback");
+    if (dev < 0 || dev >= count)
+      throw std::invalid_argument("device index out of range");
+    HIP_CHECK(hipSetDevice(dev));
+    hipDeviceProp_t prop;
+    HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+      throw NoDeviceError(std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    HIP_CHECK(hipMalloc((void **)&d_partial, 1024 * sizeof(double)));
+    HIP_CHECK(hipMalloc((void **)&d_result, 8 * sizeof(double)));
+    HIP_CHECK(hipHostMalloc((void **)&h_result, 8 * sizeof(double)));
+  }
+
+  Ctx::~Ctx()
+  {
+    (void)hipStreamSynchronize(stream);
+    for (auto &p : prof_events)
+      {
+        (void)hipEventDestroy(p.first);
+        (void)hipEventDestroy(p.second);
+      }
+    (void)hipFree(d_partial);
+    (void)hipFree(d_result);
+    (void)hipHostFree(h_result);
+    (void)hipStreamDestroy(stream);
+  }
+
+  void
+  Ctx::harvest_profile()
+  {
+    sync();
+    for (size_t i = 0; i < prof_used; ++i)
+      {
+        float ms = 0;
+        HIP_CHECK(hipEventElapsedTime(&ms, prof_events[i].first, prof_events[i].second));
+        prof_ms_accum += ms;
+      }
+    prof_n_accum += prof_used;
+    prof_used = 0;
+  }
+
+  static inline int
+  grid_for(size_t n)
+  {
+    size_t g = (n + 255) / 256;
+    if (g > 2048)
+      g = 2048;
+    if (g < 1)
+      g = 1;
+    return (int)g;
+  }
+} // namespace mgamd
+
+mgamd_vec::~mgamd_vec()
+{
+  if (data)
+    (void)hipFree(data);
+}
+
+namespace mgamd
+{
+  mgamd_vec *
+  vec_create(Ctx *ctx, size_t n, int type)
+  {
+    if (type != MGAMD_F64 && type != MGAMD_F32)
+      throw std::invalid_argument("number_type must be MGAMD_F64 or MGAMD_F32");
+    auto v  = std::make_unique<mgamd_vec>();
+    v->ctx  = ctx;
+    v->n    = n;
+    v->type = type;
+    if (n)
+      {
+        HIP_CHECK(hipMalloc(&v->data, n * (size_t)type));
+        HIP_CHECK(hipMemsetAsync(v->data, 0, n * (size_t)type, ctx->stream));
+      }
+    return v.release();
+  }
+
+  void
+  vec_set(mgamd_vec &v, double value)
+  {
+    if (!v.n)
+      return;
+    if (v.type == MGAMD_F64)
+      hipLaunchKernelGGL(vec_set_kernel<double>, grid_for(v.n), 256, 0, v.ctx->stream, v.as<double>(), value, v.n);
+    else
+      hipLaunchKernelGGL(vec_set_kernel<float>, grid_for(v.n), 256, 0, v.ctx->stream, v.as<float>(), (float)value, v.n);
+  }
+
+  void
+  vec_copy(mgamd_vec &d, const mgamd_vec &s)
+  {
+    if (d.n != s.n)
+      throw std::invalid_argument("vector size mismatch");
+    if (!d.n)
+      return;
+    const int    g  = grid_for(d.n);
+    hipStream_t  st = d.ctx->stream;
+    if (d.type == MGAMD_F64 && s.type == MGAMD_F64)
+      HIP_CHECK(hipMemcpyAsync(d.data, s.data, d.n * 8, hipMemcpyDeviceToDevice, st));
+    else if (d.type == MGAMD_F32 && s.type == MGAMD_F32)
+      HIP_CHECK(hipMemcpyAsync(d.data, s.data, d.n * 4, hipMemcpyDeviceToDevice, st));
+    else if (d.type == MGAMD_F32)
+      hipLaunchKernelGGL((vec_copy_kernel<float, double>), g, 256, 0, st, d.as<float>(), s.as<double>(), d.n);
+    else
+      hipLaunchKernelGGL((vec_copy_kernel<double, float>), g, 256, 0, st, d.as<double>(), s.as<float>(), d.n);
+  }
+
+  void
+  vec_sadd(mgamd_vec &y, double s, double a, const mgamd_vec &x)
+  {
+    if (y.n != x.n || y.type != x.type)
+      throw std::invalid_argument("vector mismatch");
+    if (!y.n)
+      return;
+    if (y.type == MGAMD_F64)
+      hipLaunchKernelGGL(vec_sadd_kernel<double>, grid_for(y.n), 256, 0, y.ctx->stream, y.as<double>(), s, a, x.as<double>(), y.n);
+    else
+      hipLaunchKernelGGL(vec_sadd_kernel<float>, grid_for(y.n), 256, 0, y.ctx->stream, y.as<float>(), (float)s, (float)a, x.as<float>(),
+                         y.n);
+  }
+
+  template <typename T>
+  static double
+  dot_raw(Ctx *ctx, const T *x, const T *y, size_t n)
+  {
+    if (!n)
+      return 0.0;
+    int g = grid_for(n);
+    if (g > 1024)
+      g = 1024;
+    hipLaunchKernelGGL(vec_dot_kernel<T>, g, 256, 0, ctx->stream, x, y, n, ctx->d_partial);
+    hipLaunchKernelGGL(vec_dot_final_kernel, 1, 256, 0, ctx->stream, ctx->d_partial, g, ctx->d_result);
+    HIP_CHECK(hipMemcpyAsync(ctx->h_result, ctx->d_result, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ctx->sync();
+    return ctx->h_result[0];
+  }
+
+  double
+  vec_dot(const mgamd_vec &x, const mgamd_vec &y)
+  {
+    if (x.n != y.n || x.type != y.type)
+      throw std::invalid_argument("vector mismatch");
+    return x.type == MGAMD_F64 ? dot_raw(x.ctx, x.as<double>(), y.as<double>(), x.n) : dot_raw(x.ctx, x.as<float>(), y.as<float>(), x.n);
+  }
+
+  void
+  LevelOperatorBase::rhs(mgamd_vec &b)
+  {
+    if (b.n != n_dofs())
+      throw std::invalid_argument("rhs: vector size mismatch");
+    std::vector<double> h;
+    tables->compute_rhs_constant(h);
+    if (b.type == MGAMD_F64)
+      HIP_CHECK(hipMemcpyAsync(b.data, h.data(), h.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    else
+      {
+        std::vector<float> f(h.begin(), h.end());
+        HIP_CHECK(hipMemcpyAsync(b.data, f.data(), f.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+      }
+    ctx->sync();
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // Level operator
+  // ------------------------------------------------------------------------------------------
+  template <typename T, int P, int B, int MODE>
+  static void
+  launch_lattice(Ctx *ctx, const ApplyArgs<T, P> &a, bool diag)
+  {
+    using G = Geo<P, B>;
+    if (a.g.n_slots == 0)
+      return;
+    const int grid = (int)((a.g.n_slots + G::SPW - 1) / G::SPW);
+    if (diag)
+      {
+        const size_t lds  = 3 * (size_t)G::SPW * G::N3 * sizeof(T);
+        auto         kern = lattice_diag_kernel<T, P, B>;
+        static bool  once = false;
+        if (!once)
+          {
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            once = true;
+          }
+        hipLaunchKernelGGL(kern, grid, G::BLOCK, lds, ctx->stream, a);
+      }
+    else
+      {
+        const size_t lds  = 2 * (size_t)G::SPW * G::N3 * sizeof(T);
+        auto         kern = lattice_apply_kernel<T, P, B, MODE>;
+        static bool  once = false;
+        if (!once)
+          {
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            once = true;
+          }
+        hipLaunchKernelGGL(kern, grid, G::BLOCK, lds, ctx->stream, a);
+      }
+    HIP_CHECK(hipGetLastError());
+  }
+
+  template <typename T, int P, int MODE>
+  static void
+  dispatch_B(Ctx *ctx, int B, const ApplyArgs<T, P> &a, bool diag)
+  {
+    switch (B)
+      {
+        case 1:
+          launch_lattice<T, P, 1, MODE>(ctx, a, diag);
+          return;
+        case 2:
+          if constexpr (P * 2 + 1 <= 17)
+            {
+              launch_lattice<T, P, 2, MODE>(ctx, a, diag);
+              return;
+            }
+          break;
+        case 4:
+          if constexpr (P * 4 + 1 <= 17)
+            {
+              launch_lattice<T, P, 4, MODE>(ctx, a, diag);
+              return;
+            }
+          break;
+        case 8:
+          if constexpr (P * 8 + 1 <= 17)
+            {
+              launch_lattice<T, P, 8, MODE>(ctx, a, diag);
+              return;
+            }
+          break;
+        case 16:
+          if constexpr (P * 16 + 1 <= 17)
+            {
+              launch_lattice<T, P, 16, MODE>(ctx, a, diag);
+              return;
+            }
+          break;
+      }
+    throw std::runtime_error("unsupported brick size");
+  }
+
+  template <typename T>
+  struct GroupDev
+  {
+    int            B = 1, N = 2;
+    size_t         n_slots = 0;
+    DBuf<uint32_t> interior_base, shell_idx;
+    DBuf<uint16_t> mask, shell_pos;
+    DBuf<double>   h;
+    SlotGroupDev
+    view() const
+    {
+      return SlotGroupDev{interior_base.p, shell_idx.p, mask.p, h.p, shell_pos.p, (uint32_t)n_slots};
+    }
+  };
+
+  template <typename T>
+  struct LevelOperator : LevelOperatorBase
+  {
+    int                                       p = 1;
+    std::vector<std::unique_ptr<GroupDev<T>>> groups;
+    DBuf<T>                                   tail_acc;
+    int                                       prof_B = 0; // brick size whose CHEB launches are profiled
+
+    LevelOperator(Ctx *c, const mgamd_dofs *dofs)
+    {
+      ctx    = c;
+      type   = (int)sizeof(T);
+      tables = dofs->tables;
+      tria   = dofs->tria;
+      p      = tables->p;
+      if (p > 4)
+        throw std::runtime_error("degrees above 4 are not instantiated in this build");
+      size_t best = 0;
+      for (const SlotGroup &g : tables->groups)
+        {
+          auto d     = std::make_unique<GroupDev<T>>();
+          d->B       = g.B;
+          d->N       = g.N;
+          d->n_slots = g.n_slots();
+          if (d->n_slots)
+            {
+              d->interior_base.upload(g.interior_base);
+              d->shell_idx.upload(g.shell_idx);
+              d->mask.upload(g.mask);
+              d->h.upload(g.h);
+              d->shell_pos.upload(g.shell_pos);
+            }
+          const size_t work = d->n_slots * (size_t)g.N * g.N * g.N;
+          if (work > best)
+            {
+              best   = work;
+              prof_B = g.B;
+            }
+          groups.push_back(std::move(d));
+        }
+      tail_acc.alloc(std::max<uint32_t>(tables->n_tail, 1));
+      tail_acc.zero(ctx->stream);
+    }
+
+    template <int P>
+    Mats<P>
+    mats() const
+    {
+      Mats<P>   m;
+      const int n = P + 1;
+      for (int i = 0; i < n * n; ++i)
+        {
+          m.M[i]  = tables->fe.M[i];
+          m.K[i]  = tables->fe.K[i];
+          m.I0[i] = tables->fe.I[0][i];
+          m.I1[i] = tables->fe.I[1][i];
+        }
+      return m;
+    }
+
+    template <int P, int MODE>
+    void
+    apply_P(const T *src, const Epilogue<T> &epi, bool diag, double words)
+    {
+      ApplyArgs<T, P> a;
+      a.m          = mats<P>();
+      a.src        = src;
+      a.tail_acc   = tail_acc.p;
+      a.n_interior = tables->n_interior;
+      a.epi        = epi;
+      for (auto &g : groups)
+        {
+          if (!g->n_slots)
+            continue;
+          a.g = g->view();
+          const bool prof = ctx->profile && !diag && MODE == MODE_CHEB && g->B == prof_B && epi.xold != nullptr;
+          if (prof)
+            {
+              if (ctx->prof_used == ctx->prof_events.size())
+                {
+                  hipEvent_t e0, e1;
+                  HIP_CHECK(hipEventCreate(&e0));
+                  HIP_CHECK(hipEventCreate(&e1));
+                  ctx->prof_events.push_back({e0, e1});
+                }
+              HIP_CHECK(hipEventRecord(ctx->prof_events[ctx->prof_used].first, ctx->stream));
+            }
+          dispatch_B<T, P, MODE>(ctx, g->B, a, diag);
+          if (prof)
+            {
+              HIP_CHECK(hipEventRecord(ctx->prof_events[ctx->prof_used].second, ctx->stream));
+              ++ctx->prof_used;
+              const double n1 = (double)(g->N - 1);
+              ctx->prof_bytes += words * sizeof(T) * (double)g->n_slots * n1 * n1 * n1;
+            }
+        }
+      const uint32_t n_rest = tables->n_dofs - tables->n_interior - tables->n_tail;
+      const uint32_t n_t    = tables->n_tail + n_rest;
+      if (n_t)
+        {
+          constexpr int TM = MODE;
+          if (diag)
+            hipLaunchKernelGGL((tail_kernel<T, MODE_INVDIAG>), grid_for(n_t), 256, 0, ctx->stream, tail_acc.p, tables->n_interior,
+                               tables->n_tail, n_rest, epi);
+          else
+            hipLaunchKernelGGL((tail_kernel<T, TM>), grid_for(n_t), 256, 0, ctx->stream, tail_acc.p, tables->n_interior, tables->n_tail,
+                               n_rest, epi);
+          HIP_CHECK(hipGetLastError());
+        }
+    }
+
+    template <int MODE>
+    void
+    apply(const T *src, const Epilogue<T> &epi, bool diag = false, double words = 0)
+    {
+      switch (p)
+        {
+          case 1:
+            apply_P<1, MODE>(src, epi, diag, words);
+            break;
+          case 2:
+            apply_P<2, MODE>(src, epi, diag, words);
+            break;
+          case 3:
+            apply_P<3, MODE>(src, epi, diag, words);
+            break;
+          case 4:
+            apply_P<4, MODE>(src, epi, diag, words);
+            break;
+          default:
+            throw std::runtime_error("degree not instantiated");
+        }
+    }
+
+    // raw-pointer entry points used by smoother / multigrid
+    void
+    vmult_raw(T *dst, const T *src)
+    {
+      Epilogue<T> e{dst, src, nullptr, nullptr, nullptr, T(0), T(0)};
+      apply<MODE_VMULT>(src, e);
+    }
+    void
+    residual_raw(T *t, const T *b, const T *x) // t = b - A x
+    {
+      Epilogue<T> e{t, x, nullptr, b, nullptr, T(0), T(0)};
+      apply<MODE_RESIDUAL>(x, e);
+    }
+    void
+    cheb_raw(T *out, const T *x, const T *xold, const T *b, const T *dinv, double f1, double f2)
+    {
+      Epilogue<T> e{out, x, xold, b, dinv, T(f1), T(f2)};
+      apply<MODE_CHEB>(x, e, false, xold ? 5.0 : 4.0);
+    }
+
+    void
+    vmult(mgamd_vec &dst, const mgamd_vec &src) override
+    {
+      if (dst.n != n_dofs() || src.n != n_dofs())
+        throw std::invalid_argument("vmult: vector size mismatch");
+      if (dst.data == src.data)
+        throw std::invalid_argument("vmult: dst and src must differ");
+      vmult_raw(dst.as<T>(), src.as<T>());
+    }
+
+    void
+    compute_inverse_diagonal(mgamd_vec &d) override
+    {
+      if (d.n != n_dofs())
+        throw std::invalid_argument("compute_inverse_diagonal: vector size mismatch");
+      Epilogue<T> e{d.as<T>(), nullptr, nullptr, nullptr, nullptr, T(0), T(0)};
+      apply<MODE_VMULT>(nullptr, e, true);
+    }
+  };
+
+  LevelOperatorBase *
+  make_level_operator(Ctx *ctx, const mgamd_dofs *dofs, int type)
+  {
+    if (type == MGAMD_F64)
+      return new LevelOperator<double>(ctx, dofs);
+    if (type == MGAMD_F32)
+      return new LevelOperator<float>(ctx, dofs);
+    throw std::invalid_argument("number_type must be MGAMD_F64 or MGAMD_F32");
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // Chebyshev smoother (deal.II PreconditionChebyshev; parameters ref:multigrid_throughput.cc:312-315,867-883)
+  // ------------------------------------------------------------------------------------------
+  static double
+  lanczos_max_eigenvalue(const std::vector<double> &alpha, const std::vector<double> &beta, double *min_ev)
+  {
+    // symmetric tridiagonal T from the CG coefficients; eigenvalues by implicit QL (tqli, no vectors)
+    const int           n = (int)alpha.size();
+    std::vector<double> d(n), e(n, 0.0);
+    for (int j = 0; j < n; ++j)
+      {
+        d[j] = 1.0 / alpha[j] + (j > 0 ? beta[j - 1] / alpha[j - 1] : 0.0);
+        if (j + 1 < n)
+          e[j] = std::sqrt(beta[j]) / alpha[j];
+      }
+    for (int l = 0; l < n; ++l)
+      {
+        int iter = 0, m;
+        do
+          {
+            for (m = l; m < n - 1; ++m)
+              {
+                const double dd = std::fabs(d[m]) + std::fabs(d[m + 1]);
+                if (std::fabs(e[m]) <= 1e-300 + 2.3e-16 * dd)
+                  break;
+              }
+            if (m != l)
+              {
+                if (iter++ == 200)
+                  throw std::runtime_error("tridiagonal eigenvalue iteration did not converge");
+                double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+                double r = std::hypot(g, 1.0);
+                g        = d[m] - d[l] + e[l] / (g + (g >= 0 ? std::fabs(r) : -std::fabs(r)));
+                double s = 1.0, c = 1.0, p = 0.0;
+                int    i;
+                for (i = m - 1; i >= l; --i)
+                  {
+                    double f = s * e[i], b = c * e[i];
+                    e[i + 1] = (r = std::hypot(f, g));
+                    if (r == 0.0)
+                      {
+                        d[i + 1] -= p;
+                        e[m] = 0.0;
+                        break;
+                      }
+                    s        = f / r;
+                    c        = g / r;
+                    g        = d[i + 1] - p;
+                    r        = (d[i] - g) * s + 2.0 * c * b;
+                    d[i + 1] = g + (p = s * r);
+                    g        = c * r - b;
+                  }
+                if (r == 0.0 && i >= l)
+                  continue;
+                d[l] -= p;
+                e[l] = g;
+                e[m] = 0.0;
+              }
+          }
+        while (m != l);
+      }
+    double mx = d[0], mn = d[0];
+    for (double v : d)
+      {
+        mx = std::max(mx, v);
+        mn = std::min(mn, v);
+      }
+    if (min_ev)
+      *min_ev = mn;
+    return mx;
+  }
+
+  template <typename T>
+  struct Chebyshev : ChebyshevBase
+  {
+    LevelOperator<T> *lop;
+    DBuf<T>           dinv, tmp;
+
+    Chebyshev(LevelOperator<T> *o, unsigned deg, double smoothing_range, unsigned eig_cg_n_iterations)
+      : lop(o)
+    {
+      op     = o;
+      degree = deg;
+      Ctx         *ctx = o->ctx;
+      const size_t n   = o->n_dofs();
+      dinv.alloc(n);
+      tmp.alloc(n);
+      {
+        // DiagonalMatrix preconditioner (ref:multigrid_throughput.cc:872-875)
+        mgamd_vec dv;
+        dv.ctx  = ctx;
+        dv.n    = n;
+        dv.type = (int)sizeof(T);
+        dv.data = dinv.p;
+        try
+          {
+            o->compute_inverse_diagonal(dv);
+          }
+        catch (...)
+          {
+            dv.data = nullptr;
+            throw;
+          }
+        dv.data = nullptr;
+      }
+      estimate_eigenvalues(smoothing_range, eig_cg_n_iterations);
+    }
+
+    void
+    estimate_eigenvalues(double smoothing_range, unsigned n_it)
+    {
+      Ctx         *ctx = lop->ctx;
+      const size_t n   = lop->n_dofs();
+      // initial guess (deal.II set_initial_guess): v_i = (i mod 11) - mean
+      std::vector<T> v(n);
+      double         sum = 0;
+      for (size_t i = 0; i < n; ++i)
+        sum += (double)(i % 11);
+      const T mean = (T)(sum / (double)n);
+      for (size_t i = 0; i < n; ++i)
+        v[i] = (T)(i % 11) - mean;
+      DBuf<T> r, z, d, Ad;
+      r.upload(v);
+      z.alloc(n);
+      d.alloc(n);
+      Ad.alloc(n);
+      std::vector<double> alphas, betas;
+      const int           g    = grid_for(n);
+      double              res0 = std::sqrt(dot_raw(ctx, r.p, r.p, n));
+      if (res0 > 0 && n_it > 0)
+        {
+          // z = D^-1 r ; d = z
+          hipLaunchKernelGGL(vec_scaled_product_kernel<T>, g, 256, 0, ctx->stream, z.p, T(1), dinv.p, r.p, n);
+          HIP_CHECK(hipMemcpyAsync(d.p, z.p, n * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
+          double rz = dot_raw(ctx, r.p, z.p, n);
+          for (unsigned it = 0; it < n_it; ++it)
+            {
+              lop->vmult_raw(Ad.p, d.p);
+              const double dAd = dot_raw(ctx, d.p, Ad.p, n);
+              if (!(dAd > 0))
+                break;
+              const double alpha = rz / dAd;
+              hipLaunchKernelGGL(vec_sadd_kernel<T>, g, 256, 0, ctx->stream, r.p, T(1), T(-alpha), Ad.p, n);
+              alphas.push_back(alpha);
+              const double res = std::sqrt(dot_raw(ctx, r.p, r.p, n));
+              if (res <= 1e-10)
+                break;
+              hipLaunchKernelGGL(vec_scaled_product_kernel<T>, g, 256, 0, ctx->stream, z.p, T(1), dinv.p, r.p, n);
+              const double rz_new = dot_raw(ctx, r.p, z.p, n);
+              const double beta   = rz_new / rz;
+              betas.push_back(beta);
+              rz = rz_new;
+              hipLaunchKernelGGL(vec_sadd_kernel<T>, g, 256, 0, ctx->stream, d.p, T(beta), T(1), z.p, n);
+            }
+        }
+      if (!alphas.empty())
+        {
+          betas.resize(alphas.size(), 0.0);
+          max_eig = lanczos_max_eigenvalue(alphas, betas, &min_eig);
+        }
+      else
+        min_eig = max_eig = 1.0;
+      max_eig *= 1.2; // safety factor, the CG is not converged
+      const double a = smoothing_range > 1.0 ? max_eig / smoothing_range : std::min(0.9 * max_eig, min_eig);
+      delta          = 0.5 * (max_eig - a);
+      theta          = 0.5 * (max_eig + a);
+      ctx->sync();
+    }
+
+    // zero initial guess; result guaranteed in S; Tb is scratch of the same size
+    void
+    vmult_raw(T *S, T *Tb, const T *b)
+    {
+      Ctx         *ctx = lop->ctx;
+      const size_t n   = lop->n_dofs();
+      T           *cur = (degree % 2 == 1) ? S : Tb;
+      T           *oth = (cur == S) ? Tb : S;
+      hipLaunchKernelGGL(vec_scaled_product_kernel<T>, grid_for(n), 256, 0, ctx->stream, cur, T(1.0 / theta), dinv.p, b, n);
+      if (degree >= 2 && std::fabs(delta) >= 1e-40)
+        {
+          double rhok = delta / theta, sigma = theta / delta;
+          for (unsigned j = 0; j + 1 < degree; ++j)
+            {
+              const double rhokp = 1.0 / (2.0 * sigma - rhok);
+              const double f1 = rhokp * rhok, f2 = 2.0 * rhokp / delta;
+              rhok = rhokp;
+              lop->cheb_raw(oth, cur, j == 0 ? nullptr : oth, b, dinv.p, f1, f2);
+              std::swap(cur, oth);
+            }
+        }
+      if (cur != S)
+        HIP_CHECK(hipMemcpyAsync(S, cur, n * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
+    }
+
+    // general initial guess x0 in X; O is scratch; returns the buffer holding the result
+    T *
+    step_raw(T *X, T *O, const T *b)
+    {
+      T *cur = X, *oth = O;
+      lop->cheb_raw(oth, cur, nullptr, b, dinv.p, 0.0, 1.0 / theta);
+      std::swap(cur, oth);
+      if (degree >= 2 && std::fabs(delta) >= 1e-40)
+        {
+          double rhok = delta / theta, sigma = theta / delta;
+          for (unsigned j = 0; j + 1 < degree; ++j)
+            {
+              const double rhokp = 1.0 / (2.0 * sigma - rhok);
+              const double f1 = rhokp * rhok, f2 = 2.0 * rhokp / delta;
+              rhok = rhokp;
+              lop->cheb_raw(oth, cur, oth, b, dinv.p, f1, f2);
+              std::swap(cur, oth);
+            }
+        }
+      return cur;
+    }
+
+    void
+    vmult(mgamd_vec &dst, const mgamd_vec &src) override
+    {
+      if (dst.n != lop->n_dofs() || src.n != lop->n_dofs() || dst.data == src.data)
+        throw std::invalid_argument("PreconditionChebyshev::vmult: bad vectors");
+      vmult_raw(dst.as<T>(), tmp.p, src.as<T>());
+    }
+    void
+    step(mgamd_vec &dst, const mgamd_vec &src) override
+    {
+      if (dst.n != lop->n_dofs() || src.n != lop->n_dofs() || dst.data == src.data)
+        throw std::invalid_argument("PreconditionChebyshev::step: bad vectors");
+      T *res = step_raw(dst.as<T>(), tmp.p, src.as<T>());
+      if (res != dst.as<T>())
+        HIP_CHECK(hipMemcpyAsync(dst.data, res, dst.n * sizeof(T), hipMemcpyDeviceToDevice, lop->ctx->stream));
+    }
+  };
+
+  ChebyshevBase *
+  make_chebyshev(LevelOperatorBase *op, unsigned degree, double smoothing_range, unsigned eig_cg_n_iterations)
+  {
+    if (degree < 1)
+      throw std::invalid_argument("SmootherDegree must be >= 1");
+    if (op->type == MGAMD_F64)
+      return new Chebyshev<double>(static_cast<LevelOperator<double> *>(op), degree, smoothing_range, eig_cg_n_iterations);
+    return new Chebyshev<float>(static_cast<LevelOperator<float> *>(op), degree, smoothing_range, eig_cg_n_iterations);
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // Two-level transfer
+  // ------------------------------------------------------------------------------------------
+  template <typename T>
+  struct Transfer2 : Transfer2Base
+  {
+    struct GroupD
+    {
+      int                 kind = 0, nf = 2;
+      size_t              n_patches = 0;
+      DBuf<uint32_t>      coarse_idx, fine_idx;
+      DBuf<uint16_t>      coarse_mask;
+      std::vector<double> E;
+    };
+    GroupD grp[3];
+    int    pc = 1, pf = 1;
+    Ctx   *ctx = nullptr;
+    FE1D   fec;
+
+    Transfer2(LevelOperator<T> *f, LevelOperator<T> *c)
+      : fec(c->tables->p)
+    {
+      fine   = f;
+      coarse = c;
+      ctx    = f->ctx;
+      TransferTables tt(*f->tables, *c->tables);
+      pc = tt.pc;
+      pf = tt.pf;
+      for (int k = 0; k < 3; ++k)
+        {
+          grp[k].kind      = k;
+          grp[k].nf        = tt.groups[k].nf;
+          grp[k].n_patches = tt.groups[k].n_patches();
+          if (grp[k].n_patches)
+            {
+              grp[k].coarse_idx.upload(tt.groups[k].coarse_idx);
+              grp[k].coarse_mask.upload(tt.groups[k].coarse_mask);
+              grp[k].fine_idx.upload(tt.groups[k].fine_idx);
+            }
+          grp[k].E = fec.embedding(k, pf);
+        }
+    }
+
+    template <int PC, int NF, bool IDENTITY>
+    void
+    launch(const GroupD &g, const T *src, T *dst, bool prolongate)
+    {
+      using G = TransferGeo<PC, NF>;
+      TransferArgs<T, PC, NF> a;
+      a.coarse_idx  = g.coarse_idx.p;
+      a.coarse_mask = g.coarse_mask.p;
+      a.fine_idx    = g.fine_idx.p;
+      a.n_patches   = (uint32_t)g.n_patches;
+      const int n   = PC + 1;
+      for (int i = 0; i < n * n; ++i)
+        {
+          a.m.M[i] = a.m.K[i] = 0.0;
+          a.m.I0[i]           = fec.I[0][i];
+          a.m.I1[i]           = fec.I[1][i];
+        }
+      if ((int)g.E.size() != NF * n)
+        throw std::runtime_error("transfer: embedding size mismatch");
+      for (int i = 0; i < NF * n; ++i)
+        a.E[i] = g.E[i];
+      a.src            = src;
+      a.dst            = dst;
+      const size_t lds = 2 * (size_t)G::SPW * G::NF3 * sizeof(T);
+      const int    grid = (int)((g.n_patches + G::SPW - 1) / G::SPW);
+      if (prolongate)
+        hipLaunchKernelGGL((prolongate_kernel<T, PC, NF, IDENTITY>), grid, G::BLOCK, lds, ctx->stream, a);
+      else
+        hipLaunchKernelGGL((restrict_kernel<T, PC, NF, IDENTITY>), grid, G::BLOCK, lds, ctx->stream, a);
+      HIP_CHECK(hipGetLastError());
+    }
+
+    void
+    run(const T *src, T *dst, bool prolongate)
+    {
+      for (int k = 0; k < 3; ++k)
+        {
+          const GroupD &g = grp[k];
+          if (!g.n_patches)
+            continue;
+          const int key = pc * 100 + g.nf;
+          if (k == 0)
+            switch (pc)
+              {
+                case 1:
+                  launch<1, 2, true>(g, src, dst, prolongate);
+                  break;
+                case 2:
+                  launch<2, 3, true>(g, src, dst, prolongate);
+                  break;
+                case 3:
+                  launch<3, 4, true>(g, src, dst, prolongate);
+                  break;
+                case 4:
+                  launch<4, 5, true>(g, src, dst, prolongate);
+                  break;
+                default:
+                  throw std::runtime_error("transfer: degree not instantiated");
+              }
+          else
+            switch (key)
+              {
+                case 103:
+                  launch<1, 3, false>(g, src, dst, prolongate);
+                  break;
+                case 104:
+                  launch<1, 4, false>(g, src, dst, prolongate);
+                  break;
+                case 205:
+                  launch<2, 5, false>(g, src, dst, prolongate);
+                  break;
+                case 307:
+                  launch<3, 7, false>(g, src, dst, prolongate);
+                  break;
+                case 409:
+                  launch<4, 9, false>(g, src, dst, prolongate);
+                  break;
+                default:
+                  throw std::runtime_error("transfer: (coarse degree, fine patch) combination not instantiated");
+              }
+        }
+    }
+
+    void
+    prolongate_raw(T *dst_fine, const T *src_coarse)
+    {
+      run(src_coarse, dst_fine, true);
+    }
+    void
+    restrict_raw(T *dst_coarse, const T *src_fine)
+    {
+      run(src_fine, dst_coarse, false);
+    }
+    void
+    prolongate_and_add(mgamd_vec &dst, const mgamd_vec &src) override
+    {
+      if (dst.n != fine->n_dofs() || src.n != coarse->n_dofs())
+        throw std::invalid_argument("prolongate_and_add: vector size mismatch");
+      prolongate_raw(dst.as<T>(), src.as<T>());
+    }
+    void
+    restrict_and_add(mgamd_vec &dst, const mgamd_vec &src) override
+    {
+      if (dst.n != coarse->n_dofs() || src.n != fine->n_dofs())
+        throw std::invalid_argument("restrict_and_add: vector size mismatch");
+      restrict_raw(dst.as<T>(), src.as<T>());
+    }
+  };
+
+  Transfer2Base *
+  make_transfer2(LevelOperatorBase *fine, LevelOperatorBase *coarse)
+  {
+    if (fine->type != coarse->type)
+      throw std::invalid_argument("transfer: level number types differ");
+    if (fine->type == MGAMD_F64)
+      return new Transfer2<double>(static_cast<LevelOperator<double> *>(fine), static_cast<LevelOperator<double> *>(coarse));
+    return new Transfer2<float>(static_cast<LevelOperator<float> *>(fine), static_cast<LevelOperator<float> *>(coarse));
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // Multigrid V-cycle  (deal.II Multigrid::level_v_step + PreconditionMG::vmult)
+  // ------------------------------------------------------------------------------------------
+  template <typename T>
+  struct MultigridT : MultigridBase
+  {
+    unsigned                         nl = 0;
+    std::vector<LevelOperator<T> *>  ops;
+    std::vector<Transfer2<T> *>      tr;
+    std::vector<Chebyshev<T> *>      sm;
+    std::vector<std::unique_ptr<DBuf<T>>> defect, S, Tb, res;
+    std::vector<T *>                 sol; // where the level solution currently lives
+    std::string                      coarse_type;
+    DBuf<double>                     coarse_inv; // dense inverse for "direct"
+    DBuf<T>                          cg_r, cg_z, cg_p, cg_Ap;
+    hipGraphExec_t                   graph_exec = nullptr;
+    const void                      *graph_z = nullptr, *graph_r = nullptr;
+
+    MultigridT(Ctx *c, unsigned n_levels, LevelOperatorBase *const *levels, Transfer2Base *const *transfers,
+               ChebyshevBase *const *smoothers, const std::string &coarse)
+    {
+      ctx = c;
+      nl  = n_levels;
+      if (nl < 1)
+        throw std::invalid_argument("multigrid: need at least one level");
+      for (unsigned l = 0; l < nl; ++l)
+        {
+          if (!levels[l] || levels[l]->type != (int)sizeof(T))
+            throw std::invalid_argument("multigrid: level operators must share one number type");
+          ops.push_back(static_cast<LevelOperator<T> *>(levels[l]));
+          tr.push_back(l > 0 ? static_cast<Transfer2<T> *>(transfers[l]) : nullptr);
+          sm.push_back(smoothers[l] ? static_cast<Chebyshev<T> *>(smoothers[l]) : nullptr);
+          if (l > 0 && (!transfers[l] || !smoothers[l]))
+            throw std::invalid_argument("multigrid: missing transfer or smoother");
+          if (l > 0 && (transfers[l]->fine != levels[l] || transfers[l]->coarse != levels[l - 1]))
+            throw std::invalid_argument("multigrid: transfer does not connect the given levels");
+          const size_t n = ops[l]->n_dofs();
+          defect.emplace_back(new DBuf<T>);
+          S.emplace_back(new DBuf<T>);
+          Tb.emplace_back(new DBuf<T>);
+          res.emplace_back(new DBuf<T>);
+          defect[l]->alloc(n);
+          S[l]->alloc(n);
+          Tb[l]->alloc(n);
+          res[l]->alloc(n);
+        }
+      sol.assign(nl, nullptr);
+      coarse_type = coarse;
+      if (coarse == "amg" || coarse == "cg_with_amg" || coarse == "amg_petsc")
+        coarse_type = "direct"; // 1-cell coarse level: ML/BoomerAMG degenerate to a direct solve
+      if (coarse_type == "direct")
+        setup_direct();
+      else if (coarse_type == "cg" || coarse_type == "cg_with_chebyshev")
+        {
+          const size_t n = ops[0]->n_dofs();
+          cg_r.alloc(n);
+          cg_z.alloc(n);
+          cg_p.alloc(n);
+          cg_Ap.alloc(n);
+          if (coarse_type == "cg_with_chebyshev" && !sm[0])
+            throw std::invalid_argument("multigrid: cg_with_chebyshev needs a smoother on level 0");
+        }
+      else
+        throw std::invalid_argument("CoarseGridSolverType '" + coarse + "' not implemented");
+    }
+
+    ~MultigridT() override
+    {
+      if (graph_exec)
+        (void)hipGraphExecDestroy(graph_exec);
+    }
+
+    void
+    setup_direct()
+    {
+      const size_t n = ops[0]->n_dofs();
+      if (n > 4096)
+        throw std::runtime_error("coarse level too large for the direct solver (" + std::to_string(n) +
+                                 " DoFs): use CoarseGridSolverType cg or cg_with_chebyshev");
+      // dense A_0 column by column through the level operator
+      std::vector<double> A(n * n, 0.0);
+      DBuf<T>             e, col;
+      e.alloc(n);
+      col.alloc(n);
+      std::vector<T> h(n);
+      for (size_t j = 0; j < n; ++j)
+        {
+          e.zero(ctx->stream);
+          const T one = T(1);
+          HIP_CHECK(hipMemcpyAsync(e.p + j, &one, sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+          ops[0]->vmult_raw(col.p, e.p);
+          HIP_CHECK(hipMemcpyAsync(h.data(), col.p, n * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+          ctx->sync();
+          for (size_t i = 0; i < n; ++i)
+            A[i * n + j] = (double)h[i];
+        }
+      // symmetrise and invert by Gauss-Jordan with partial pivoting
+      for (size_t i = 0; i < n; ++i)
+        for (size_t j = i + 1; j < n; ++j)
+          A[i * n + j] = A[j * n + i] = 0.5 * (A[i * n + j] + A[j * n + i]);
+      std::vector<double> inv(n * n, 0.0);
+      for (size_t i = 0; i < n; ++i)
+        inv[i * n + i] = 1.0;
+      for (size_t c = 0; c < n; ++c)
+        {
+          size_t piv = c;
+          for (size_t r = c + 1; r < n; ++r)
+            if (std::fabs(A[r * n + c]) > std::fabs(A[piv * n + c]))
+              piv = r;
+          if (std::fabs(A[piv * n + c]) < 1e-300)
+            throw std::runtime_error("coarse matrix is singular");
+          if (piv != c)
+            for (size_t k = 0; k < n; ++k)
+              {
+                std::swap(A[c * n + k], A[piv * n + k]);
+                std::swap(inv[c * n + k], inv[piv * n + k]);
+              }
+          const double d = 1.0 / A[c * n + c];
+          for (size_t k = 0; k < n; ++k)
+            {
+              A[c * n + k] *= d;
+              inv[c * n + k] *= d;
+            }
+          for (size_t r = 0; r < n; ++r)
+            if (r != c)
+              {
+                const double f = A[r * n + c];
+                if (f != 0.0)
+                  for (size_t k = 0; k < n; ++k)
+                    {
+                      A[r * n + k] -= f * A[c * n + k];
+                      inv[r * n + k] -= f * inv[c * n + k];
+                    }
+              }
+        }
+      coarse_inv.upload(inv);
+    }
+
+    void
+    stage(int s, bool start, unsigned level)
+    {
+      if (cb)
+        {
+          ctx->sync();
+          cb(s, start ? 1 : 0, level, cb_user);
+        }
+    }
+
+    void
+    coarse_cg(T *x, const T *b, bool with_cheb)
+    {
+      // SolverCG + ReductionControl(maxiter 10000, abstol 1e-20, reltol 1e-4): ref:multigrid_throughput.cc:888-895
+      const size_t n = ops[0]->n_dofs();
+      const int    g = grid_for(n);
+      HIP_CHECK(hipMemsetAsync(x, 0, n * sizeof(T), ctx->stream));
+      HIP_CHECK(hipMemcpyAsync(cg_r.p, b, n * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
+      const double res0 = std::sqrt(dot_raw(ctx, cg_r.p, cg_r.p, n));
+      if (res0 <= 1e-20)
+        return;
+      auto precond = [&]() {
+        if (with_cheb)
+          sm[0]->vmult_raw(cg_z.p, sm[0]->tmp.p, cg_r.p);
+        else
+          HIP_CHECK(hipMemcpyAsync(cg_z.p, cg_r.p, n * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
+      };
+      precond();
+      HIP_CHECK(hipMemcpyAsync(cg_p.p, cg_z.p, n * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
+      double rz = dot_raw(ctx, cg_r.p, cg_z.p, n);
+      for (unsigned it = 1; it <= 10000; ++it)
+        {
+          ops[0]->vmult_raw(cg_Ap.p, cg_p.p);
+          const double alpha = rz / dot_raw(ctx, cg_p.p, cg_Ap.p, n);
+          hipLaunchKernelGGL(vec_sadd_kernel<T>, g, 256, 0, ctx->stream, x, T(1), T(alpha), cg_p.p, n);
+          hipLaunchKernelGGL(vec_sadd_kernel<T>, g, 256, 0, ctx->stream, cg_r.p, T(1), T(-alpha), cg_Ap.p, n);
+          const double res = std::sqrt(dot_raw(ctx, cg_r.p, cg_r.p, n));
+          if (res < 1e-4 * res0 || res <= 1e-20)
+            break;
+          precond();
+          const double rz_new = dot_raw(ctx, cg_r.p, cg_z.p, n);
+          const double beta   = rz_new / rz;
+          rz                  = rz_new;
+          hipLaunchKernelGGL(vec_sadd_kernel<T>, g, 256, 0, ctx->stream, cg_p.p, T(beta), T(1), cg_z.p, n);
+        }
+    }
+
+    // the cycle on level vectors; defect[nl-1] must be set, coarser defects zero
+    void
+    level_v_step(unsigned l)
+    {
+      if (l == 0)
+        {
+          stage(3, true, 0);
+          const size_t n = ops[0]->n_dofs();
+          if (coarse_type == "direct")
+            hipLaunchKernelGGL(dense_matvec_kernel<T>, (int)std::min<size_t>(n, 1024), 256, 0, ctx->stream, coarse_inv.p, defect[0]->p,
+                               S[0]->p, (int)n);
+          else
+            coarse_cg(S[0]->p, defect[0]->p, coarse_type == "cg_with_chebyshev");
+          sol[0] = S[0]->p;
+          stage(3, false, 0);
+          return;
+        }
+      stage(0, true, l);
+      sm[l]->vmult_raw(S[l]->p, Tb[l]->p, defect[l]->p); // pre-smoothing, zero start
+      stage(0, false, l);
+      stage(1, true, l);
+      ops[l]->residual_raw(res[l]->p, defect[l]->p, S[l]->p); // t = d - A x
+      stage(1, false, l);
+      stage(2, true, l);
+      tr[l]->restrict_raw(defect[l - 1]->p, res[l]->p);
+      stage(2, false, l);
+      level_v_step(l - 1);
+      stage(4, true, l);
+      tr[l]->prolongate_raw(S[l]->p, sol[l - 1]);
+      stage(4, false, l);
+      stage(5, true, l); // edge_prolongation: no-op for global coarsening (ref:multigrid_throughput.cc:1126-1130)
+      stage(5, false, l);
+      stage(6, true, l);
+      sol[l] = sm[l]->step_raw(S[l]->p, Tb[l]->p, defect[l]->p); // post-smoothing
+      stage(6, false, l);
+    }
+
+    template <typename TO>
+    void
+    vcycle_raw(TO *z, const TO *r)
+    {
+      const size_t n = ops[nl - 1]->n_dofs();
+      // copy_to_mg: defect_L = cast(r), coarser defects zero
+      if (cb)
+        {
+          ctx->sync();
+          cb(7, 1, nl - 1, cb_user);
+        }
+      if (sizeof(TO) == sizeof(T))
+        HIP_CHECK(hipMemcpyAsync(defect[nl - 1]->p, r, n * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
+      else
+        hipLaunchKernelGGL((vec_copy_kernel<T, TO>), grid_for(n), 256, 0, ctx->stream, defect[nl - 1]->p, r, n);
+      for (unsigned l = 0; l + 1 < nl; ++l)
+        defect[l]->zero(ctx->stream);
+      if (cb)
+        {
+          ctx->sync();
+          cb(7, 0, nl - 1, cb_user);
+        }
+      level_v_step(nl - 1);
+      if (cb)
+        {
+          ctx->sync();
+          cb(8, 1, nl - 1, cb_user);
+        }
+      if (sizeof(TO) == sizeof(T))
+        HIP_CHECK(hipMemcpyAsync(z, sol[nl - 1], n * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
+      else
+        hipLaunchKernelGGL((vec_copy_kernel<TO, T>), grid_for(n), 256, 0, ctx->stream, z, sol[nl - 1], n);
+      if (cb)
+        {
+          ctx->sync();
+          cb(8, 0, nl - 1, cb_user);
+        }
+    }
+
+    void
+    vcycle(mgamd_vec &z, const mgamd_vec &r) override
+    {
+      const size_t n = ops[nl - 1]->n_dofs();
+      if (z.n != n || r.n != n || z.type != r.type || z.data == r.data)
+        throw std::invalid_argument("PreconditionMG::vmult: bad vectors");
+      if (z.type == MGAMD_F64)
+        vcycle_raw<double>(z.as<double>(), r.as<double>());
+      else
+        vcycle_raw<float>(z.as<float>(), r.as<float>());
+    }
+
+    double
+    time_vcycles(mgamd_vec &z, const mgamd_vec &r, unsigned n, bool use_graph) override
+    {
+      if (n == 0)
+        return 0.0;
+      if (cb)
+        throw std::invalid_argument("time_vcycles: remove the stage callback first");
+      const bool graphable = coarse_type == "direct";
+      vcycle(z, r); // warm-up: sets kernel attributes, touches memory
+      ctx->sync();
+      if (use_graph && graphable && (!graph_exec || graph_z != z.data || graph_r != r.data))
+        {
+          if (graph_exec)
+            {
+              (void)hipGraphExecDestroy(graph_exec);
+              graph_exec = nullptr;
+            }
+          hipGraph_t graph;
+          HIP_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+          const bool saved = ctx->profile;
+          ctx->profile     = false;
+          try
+            {
+              vcycle(z, r);
+            }
+          catch (...)
+            {
+              ctx->profile = saved;
+              (void)hipStreamEndCapture(ctx->stream, &graph);
+              throw;
+            }
+          ctx->profile = saved;
+          HIP_CHECK(hipStreamEndCapture(ctx->stream, &graph));
+          HIP_CHECK(hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0));
+          HIP_CHECK(hipGraphDestroy(graph));
+          graph_z = z.data;
+          graph_r = r.data;
+          HIP_CHECK(hipGraphLaunch(graph_exec, ctx->stream));
+          ctx->sync();
+        }
+      hipEvent_t e0, e1;
+      HIP_CHECK(hipEventCreate(&e0));
+      HIP_CHECK(hipEventCreate(&e1));
+      HIP_CHECK(hipEventRecord(e0, ctx->stream));
+      for (unsigned i = 0; i < n; ++i)
+        {
+          if (use_graph && graphable)
+            HIP_CHECK(hipGraphLaunch(graph_exec, ctx->stream));
+          else
+            vcycle(z, r);
+        }
+      HIP_CHECK(hipEventRecord(e1, ctx->stream));
+      HIP_CHECK(hipEventSynchronize(e1));
+      float ms = 0;
+      HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+      (void)hipEventDestroy(e0);
+      (void)hipEventDestroy(e1);
+      return (double)ms / n;
+    }
+  };
+
+  MultigridBase *
+  make_multigrid(Ctx *ctx, unsigned n_levels, LevelOperatorBase *const *levels, Transfer2Base *const *transfers,
+                 ChebyshevBase *const *smoothers, const std::string &coarse_solver)
+  {
+    if (!n_levels || !levels || !levels[0])
+      throw std::invalid_argument("multigrid: no levels");
+    if (levels[0]->type == MGAMD_F64)
+      return new MultigridT<double>(ctx, n_levels, levels, transfers, smoothers, coarse_solver);
+    return new MultigridT<float>(ctx, n_levels, levels, transfers, smoothers, coarse_solver);
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // Outer solver: deal.II SolverCG + ReductionControl (ref:multigrid_throughput.cc:1140-1147,1625-1635)
+  // ------------------------------------------------------------------------------------------
+  void
+  solve_cg(LevelOperatorBase &A, MultigridBase *M, mgamd_vec &x, const mgamd_vec &b, double reltol, double abstol, unsigned maxiter,
+           unsigned &n_iterations, double &residual)
+  {
+    Ctx         *ctx = A.ctx;
+    const size_t n   = A.n_dofs();
+    if (x.n != n || b.n != n || x.type != A.type || b.type != A.type)
+      throw std::invalid_argument("SolverCG::solve: bad vectors");
+    std::unique_ptr<mgamd_vec> g(vec_create(ctx, n, A.type)), h(vec_create(ctx, n, A.type)), d(vec_create(ctx, n, A.type)),
+      Ad(vec_create(ctx, n, A.type));
+    vec_set(x, 0.0); // dst = 0 (ref:multigrid_throughput.cc:1142,1245)
+    vec_copy(*g, b); // residual r = b - A*0
+    double res   = std::sqrt(vec_dot(*g, *g));
+    const double res0 = res;
+    n_iterations = 0;
+    residual     = res;
+    if (res <= abstol)
+      return;
+    auto precond = [&]() {
+      if (M)
+        M->vcycle(*h, *g);
+      else
+        vec_copy(*h, *g);
+    };
+    precond();
+    vec_copy(*d, *h);
+    double gh = vec_dot(*g, *h);
+    for (unsigned it = 1; it <= maxiter; ++it)
+      {
+        A.vmult(*Ad, *d);
+        const double alpha = gh / vec_dot(*d, *Ad);
+        vec_sadd(x, 1.0, alpha, *d);
+        vec_sadd(*g, 1.0, -alpha, *Ad);
+        res          = std::sqrt(vec_dot(*g, *g));
+        n_iterations = it;
+        residual     = res;
+        if (res < reltol * res0 || res <= abstol)
+          break;
+        precond();
+        const double gh_new = vec_dot(*g, *h);
+        const double beta   = gh_new / gh;
+        gh                  = gh_new;
+        vec_sadd(*d, beta, 1.0, *h);
+      }
+    ctx->sync();
+  }
+} // namespace mgamd

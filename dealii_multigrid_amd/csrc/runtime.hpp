@@ -1,0 +1,230 @@
+// Device runtime: HIP stream + device vectors + the objects behind the C ABI.
+// Class and method names follow deal.II's plugin surface as the reference uses it
+// (SURVEY.md section 8b): LevelOperator <-> Operator<3,1,Number> (ref:include/operator.h),
+// Chebyshev <-> PreconditionChebyshev, Transfer2 <-> MGTwoLevelTransfer,
+// Multigrid <-> Multigrid + PreconditionMG + MGTransferGlobalCoarsening, solve_cg <-> SolverCG.
+#pragma once
+#include "api_common.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <functional>
+#include <map>
+#include <sstream>
+
+namespace mgamd
+{
+#define HIP_CHECK(expr)                                                                                       \
+  do                                                                                                          \
+    {                                                                                                         \
+      hipError_t e_ = (expr);                                                                                 \
+      if (e_ != hipSuccess)                                                                                   \
+        {                                                                                                     \
+          std::ostringstream os_;                                                                             \
+          os_ << "HIP error " << hipGetErrorString(e_) << " at " << __FILE__ << ":" << __LINE__ << ": " #expr; \
+          throw std::runtime_error(os_.str());                                                                \
+        }                                                                                                     \
+    }                                                                                                         \
+  while (0)
+
+  struct Ctx
+  {
+    int         device = 0;
+    hipStream_t stream = nullptr;
+    double     *d_partial = nullptr; // 1024 block partials
+    double     *d_result  = nullptr; // 8 scalars
+    double     *h_result  = nullptr; // pinned
+    // dominant-kernel profiling (HIP events around the largest lattice_apply launches)
+    bool                                           profile = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+    size_t                                         prof_used  = 0;
+    double                                         prof_bytes = 0.0;
+    double                                         prof_ms_accum = 0.0; // already harvested
+    uint64_t                                       prof_n_accum  = 0;
+
+    explicit Ctx(int dev);
+    ~Ctx();
+    void
+    sync()
+    {
+      HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    void
+    harvest_profile();
+  };
+
+  template <typename T>
+  struct DBuf
+  {
+    T     *p = nullptr;
+    size_t n = 0;
+    DBuf() = default;
+    DBuf(const DBuf &) = delete;
+    DBuf &
+    operator=(const DBuf &) = delete;
+    ~DBuf()
+    {
+      if (p)
+        (void)hipFree(p);
+    }
+    void
+    alloc(size_t count)
+    {
+      if (p)
+        (void)hipFree(p);
+      p = nullptr;
+      n = count;
+      if (count)
+        HIP_CHECK(hipMalloc((void **)&p, count * sizeof(T)));
+    }
+    void
+    upload(const std::vector<T> &h)
+    {
+      alloc(h.size());
+      if (n)
+        HIP_CHECK(hipMemcpy(p, h.data(), n * sizeof(T), hipMemcpyHostToDevice));
+    }
+    void
+    zero(hipStream_t s)
+    {
+      if (n)
+        HIP_CHECK(hipMemsetAsync(p, 0, n * sizeof(T), s));
+    }
+  };
+} // namespace mgamd
+
+// ---- opaque handles -------------------------------------------------------------------------
+struct mgamd_ctx
+{
+  std::unique_ptr<mgamd::Ctx> ctx;
+};
+
+struct mgamd_vec
+{
+  mgamd::Ctx *ctx  = nullptr;
+  size_t      n    = 0;
+  int         type = MGAMD_F64;
+  void       *data = nullptr;
+  ~mgamd_vec();
+  template <typename T>
+  T *
+  as()
+  {
+    check<T>();
+    return static_cast<T *>(data);
+  }
+  template <typename T>
+  const T *
+  as() const
+  {
+    check<T>();
+    return static_cast<const T *>(data);
+  }
+  template <typename T>
+  void
+  check() const
+  {
+    if ((int)sizeof(T) != type)
+      throw std::invalid_argument("vector number type does not match the operator's");
+  }
+};
+
+namespace mgamd
+{
+  mgamd_vec *
+  vec_create(Ctx *ctx, size_t n, int type);
+
+  // launch helpers on type-erased vectors
+  void
+  vec_set(mgamd_vec &v, double value);
+  void
+  vec_copy(mgamd_vec &dst, const mgamd_vec &src);
+  void
+  vec_sadd(mgamd_vec &y, double s, double a, const mgamd_vec &x);
+  double
+  vec_dot(const mgamd_vec &x, const mgamd_vec &y);
+
+  struct LevelOperatorBase
+  {
+    Ctx                         *ctx  = nullptr;
+    int                          type = MGAMD_F64;
+    std::shared_ptr<LevelTables> tables;
+    std::shared_ptr<Tria>        tria;
+    virtual ~LevelOperatorBase() = default;
+    uint32_t
+    n_dofs() const
+    {
+      return tables->n_dofs;
+    }
+    virtual void
+    vmult(mgamd_vec &dst, const mgamd_vec &src) = 0;
+    virtual void
+    compute_inverse_diagonal(mgamd_vec &d) = 0;
+    void
+    rhs(mgamd_vec &b);
+  };
+
+  struct ChebyshevBase
+  {
+    virtual ~ChebyshevBase() = default;
+    LevelOperatorBase *op = nullptr;
+    unsigned           degree = 3;
+    double             min_eig = 0, max_eig = 0, theta = 1, delta = 0;
+    virtual void
+    vmult(mgamd_vec &dst, const mgamd_vec &src) = 0;
+    virtual void
+    step(mgamd_vec &dst, const mgamd_vec &src) = 0;
+  };
+
+  struct Transfer2Base
+  {
+    virtual ~Transfer2Base() = default;
+    LevelOperatorBase *fine = nullptr, *coarse = nullptr;
+    virtual void
+    prolongate_and_add(mgamd_vec &dst_fine, const mgamd_vec &src_coarse) = 0;
+    virtual void
+    restrict_and_add(mgamd_vec &dst_coarse, const mgamd_vec &src_fine) = 0;
+  };
+
+  struct MultigridBase
+  {
+    virtual ~MultigridBase() = default;
+    Ctx                 *ctx = nullptr;
+    mgamd_stage_callback cb  = nullptr;
+    void                *cb_user = nullptr;
+    virtual void
+    vcycle(mgamd_vec &z, const mgamd_vec &r) = 0; // PreconditionMG::vmult
+    virtual double
+    time_vcycles(mgamd_vec &z, const mgamd_vec &r, unsigned n, bool use_graph) = 0;
+  };
+
+  LevelOperatorBase *
+  make_level_operator(Ctx *ctx, const mgamd_dofs *dofs, int type);
+  ChebyshevBase *
+  make_chebyshev(LevelOperatorBase *op, unsigned degree, double smoothing_range, unsigned eig_cg_n_iterations);
+  Transfer2Base *
+  make_transfer2(LevelOperatorBase *fine, LevelOperatorBase *coarse);
+  MultigridBase *
+  make_multigrid(Ctx *ctx, unsigned n_levels, LevelOperatorBase *const *levels, Transfer2Base *const *transfers,
+                 ChebyshevBase *const *smoothers, const std::string &coarse_solver);
+  void
+  solve_cg(LevelOperatorBase &A, MultigridBase *M, mgamd_vec &x, const mgamd_vec &b, double reltol, double abstol, unsigned maxiter,
+           unsigned &n_iterations, double &residual);
+} // namespace mgamd
+
+struct mgamd_level_op
+{
+  std::unique_ptr<mgamd::LevelOperatorBase> op;
+};
+struct mgamd_cheb
+{
+  std::unique_ptr<mgamd::ChebyshevBase> c;
+};
+struct mgamd_transfer2
+{
+  std::unique_ptr<mgamd::Transfer2Base> t;
+};
+struct mgamd_mg
+{
+  std::unique_ptr<mgamd::MultigridBase> mg;
+};

@@ -1,0 +1,206 @@
+"""GPU parity tests: every HIP kernel behind the C ABI against the numpy/scipy oracle on the same inputs.
+Tolerances are FP64 rounding-level (north_star: solution within a stated FP64 tolerance, CG iteration counts equal):
+  single operator application   <= 1e-13 relative
+  converged CG solution         <= 1e-10 relative (l2), iteration counts equal
+"""
+import numpy as np
+import pytest
+
+from conftest import oracle_level, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL_OP = 1e-13
+TOL_SOL = 1e-10
+
+OP_CASES = [("quadrant", 3, 1, 0), ("quadrant", 3, 1, 1), ("quadrant", 4, 1, 0), ("quadrant", 3, 2, 0), ("quadrant", 3, 3, 0),
+            ("quadrant", 3, 4, 0), ("quadrant", 3, 4, 1), ("hypercube", 3, 1, 0), ("hypercube", 4, 1, 0), ("hypercube", 2, 4, 0),
+            ("hypercube", 3, 2, 0), ("annulus", 5, 2, 0), ("annulus", 5, 1, 0), ("quadrant", 0, 4, 0), ("quadrant", 1, 1, 0)]
+
+
+@pytest.fixture(scope="module")
+def levels(mgamd, oracle, ctx):
+    cache = {}
+
+    def get(geo, L, p, max_brick):
+        key = (geo, L, p, max_brick)
+        if key not in cache:
+            t = mgamd.Triangulation(geo, L)
+            d = mgamd.DoFs(t, p, max_brick)
+            cache[key] = (d, mgamd.Operator(ctx, d), oracle_level(oracle, d, geo, L, p))
+        return cache[key]
+
+    return get
+
+
+@pytest.mark.parametrize("geo,L,p,max_brick", OP_CASES)
+def test_vmult(mgamd, ctx, levels, geo, L, p, max_brick):
+    d, op, lv = levels(geo, L, p, max_brick)
+    assert op.m() == lv.n
+    rng = np.random.default_rng(3)
+    for trial in range(2):
+        x = rng.standard_normal(lv.n)
+        src, dst = op.initialize_dof_vector().from_host(x), op.initialize_dof_vector()
+        dst.set(7.0)  # vmult must overwrite
+        op.vmult(dst, src)
+        assert rel_err(dst.to_host(), lv.A @ x) < TOL_OP
+        assert np.array_equal(src.to_host(), x)  # src untouched
+
+
+@pytest.mark.parametrize("geo,L,p,max_brick", OP_CASES)
+def test_inverse_diagonal(mgamd, ctx, levels, geo, L, p, max_brick):
+    d, op, lv = levels(geo, L, p, max_brick)
+    diag = op.initialize_dof_vector()
+    op.compute_inverse_diagonal(diag)
+    assert rel_err(diag.to_host(), lv.inv_diag) < TOL_OP
+
+
+@pytest.mark.parametrize("geo,L,p,max_brick", OP_CASES[:8])
+def test_rhs(mgamd, ctx, levels, geo, L, p, max_brick):
+    d, op, lv = levels(geo, L, p, max_brick)
+    b = op.initialize_dof_vector()
+    op.rhs(b)
+    assert np.abs(b.to_host() - lv.rhs_constant).max() < 1e-15
+
+
+def test_vector_ops(mgamd, ctx):
+    rng = np.random.default_rng(4)
+    n = 100003
+    a, b = rng.standard_normal(n), rng.standard_normal(n)
+    va, vb = mgamd.Vector(ctx, n).from_host(a), mgamd.Vector(ctx, n).from_host(b)
+    assert va.dot(vb) == pytest.approx(a @ b, rel=1e-13)
+    assert va.l2_norm() == pytest.approx(np.linalg.norm(a), rel=1e-14)
+    va.sadd(0.5, -2.0, vb)
+    assert np.allclose(va.to_host(), 0.5 * a - 2.0 * b, rtol=0, atol=1e-15)
+    vf = mgamd.Vector(ctx, n, mgamd.F32)
+    vf.copy_from(vb)
+    assert np.array_equal(vf.to_host(), b.astype(np.float32).astype(np.float64))
+    assert mgamd.Vector(ctx, 0).dot(mgamd.Vector(ctx, 0)) == 0.0  # empty vectors
+
+
+@pytest.mark.parametrize("geo,L,p,max_brick", [("quadrant", 3, 1, 0), ("quadrant", 3, 4, 0), ("hypercube", 3, 2, 0), ("annulus", 5, 2, 0)])
+@pytest.mark.parametrize("degree", [1, 2, 3, 4])
+def test_chebyshev(mgamd, oracle, ctx, levels, geo, L, p, max_brick, degree):
+    d, op, lv = levels(geo, L, p, max_brick)
+    ch = mgamd.PreconditionChebyshev(op, degree, 20.0, 20)
+    ref = oracle.Chebyshev(lv.A, lv.inv_diag, degree, 20.0, 20)
+    lo, hi = ch.eigenvalue_estimates()
+    assert hi == pytest.approx(ref.max_ev, rel=1e-10)
+    rng = np.random.default_rng(5)
+    b, x0 = rng.standard_normal(lv.n), rng.standard_normal(lv.n)
+    vb, vx = op.initialize_dof_vector().from_host(b), op.initialize_dof_vector()
+    ch.vmult(vx, vb)
+    assert rel_err(vx.to_host(), ref.vmult(b)) < 1e-12
+    vx.from_host(x0)
+    ch.step(vx, vb)
+    assert rel_err(vx.to_host(), ref.step(x0, b)) < 1e-12
+
+
+HIER_CASES = [("quadrant", 3, 1, "HMG-global"), ("quadrant", 4, 1, "HMG-global"), ("quadrant", 3, 2, "HMG-global"),
+              ("quadrant", 3, 4, "HMG-global"), ("hypercube", 3, 1, "HMG-global"), ("hypercube", 2, 4, "HMG-global"),
+              ("annulus", 5, 2, "HMG-global"), ("quadrant", 3, 4, "PMG"), ("annulus", 5, 2, "PMG"), ("quadrant", 3, 3, "PMG")]
+
+
+@pytest.fixture(scope="module")
+def hierarchies(mgamd, oracle, ctx):
+    cache = {}
+
+    def get(geo, L, p, mg_type, coarse="amg"):
+        key = (geo, L, p, mg_type, coarse)
+        if key not in cache:
+            h = mgamd.Hierarchy(ctx, geo, L, p, mg_type, coarse_solver=coarse)
+            keys = [d.keys() for d in h.dofs]
+            levels, P = oracle.build_hierarchy(geo, L, p, mg_type, numbering_keys=keys)
+            cache[key] = (h, levels, P)
+        return cache[key]
+
+    return get
+
+
+@pytest.mark.parametrize("geo,L,p,mg_type", HIER_CASES)
+def test_transfer(mgamd, ctx, hierarchies, geo, L, p, mg_type):
+    h, levels, P = hierarchies(geo, L, p, mg_type)
+    rng = np.random.default_rng(6)
+    for l in range(1, len(levels)):
+        xc, xf0 = rng.standard_normal(levels[l - 1].n), rng.standard_normal(levels[l].n)
+        vc, vf = h.operators[l - 1].initialize_dof_vector().from_host(xc), h.operators[l].initialize_dof_vector().from_host(xf0)
+        h.transfers[l].prolongate_and_add(vf, vc)
+        assert rel_err(vf.to_host(), xf0 + P[l] @ xc) < TOL_OP
+        rf, dc0 = rng.standard_normal(levels[l].n), rng.standard_normal(levels[l - 1].n)
+        vr, vd = h.operators[l].initialize_dof_vector().from_host(rf), h.operators[l - 1].initialize_dof_vector().from_host(dc0)
+        h.transfers[l].restrict_and_add(vd, vr)
+        assert rel_err(vd.to_host(), dc0 + P[l].T @ rf) < TOL_OP
+
+
+@pytest.mark.parametrize("geo,L,p,mg_type", HIER_CASES)
+def test_vcycle(mgamd, oracle, ctx, hierarchies, geo, L, p, mg_type):
+    h, levels, P = hierarchies(geo, L, p, mg_type)
+    mg = oracle.Multigrid(levels, P, 3, coarse="direct")
+    for l, s in enumerate(h.smoothers):
+        assert s.eigenvalue_estimates()[1] == pytest.approx(mg.sm[l].max_ev, rel=1e-9)
+    r = np.random.default_rng(7).standard_normal(levels[-1].n)
+    vr, vz = mgamd.Vector(ctx, levels[-1].n).from_host(r), mgamd.Vector(ctx, levels[-1].n)
+    h.mg.vmult(vz, vr)
+    ref = mg.vcycle(r)
+    assert rel_err(vz.to_host(), ref) < 1e-11
+    # stage callbacks (Multigrid::connect_* in the reference) fire in V-cycle order and do not change the result
+    events = []
+    h.mg.connect_stages(lambda s, start, lv: events.append((s, start, lv)))
+    h.mg.vmult(vz, vr)
+    h.mg.connect_stages(None)
+    assert rel_err(vz.to_host(), ref) < 1e-11
+    nl = len(levels)
+    assert events[0] == (7, True, nl - 1) and events[-1] == (8, False, nl - 1)
+    assert [e for e in events if e[0] == 3] == [(3, True, 0), (3, False, 0)]
+    assert sum(1 for e in events if e[0] == 0 and e[1]) == nl - 1
+    # graph replay gives the same vector
+    ms = h.mg.time_vcycles(vz, vr, 2, True)
+    assert ms > 0 and rel_err(vz.to_host(), ref) < 1e-11
+
+
+@pytest.mark.parametrize("geo,L,p,mg_type", HIER_CASES)
+def test_cg_solve_iteration_counts_and_solution(mgamd, oracle, ctx, hierarchies, geo, L, p, mg_type):
+    h, levels, P = hierarchies(geo, L, p, mg_type)
+    mg = oracle.Multigrid(levels, P, 3, coarse="direct")
+    Lf = levels[-1]
+    xref, itref, hist = oracle.pcg(Lf.A, Lf.rhs_constant, mg.vcycle, 1e-4)
+    b, x = h.fine_operator.initialize_dof_vector(), h.fine_operator.initialize_dof_vector()
+    h.fine_operator.rhs(b)
+    it, res = mgamd.solve_cg(h.fine_operator, h.mg, x, b, 1e-4)
+    assert it == itref
+    assert res == pytest.approx(hist[-1], rel=1e-6)
+    assert rel_err(x.to_host(), xref) < TOL_SOL
+
+
+@pytest.mark.parametrize("coarse", ["cg", "cg_with_chebyshev"])
+def test_trilinos_free_coarse_solvers(mgamd, oracle, ctx, hierarchies, coarse):
+    h, levels, P = hierarchies("annulus", 5, 2, "PMG", coarse)
+    mg = oracle.Multigrid(levels, P, 3, coarse=coarse)
+    Lf = levels[-1]
+    xref, itref, hist = oracle.pcg(Lf.A, Lf.rhs_constant, mg.vcycle, 1e-4)
+    b, x = h.fine_operator.initialize_dof_vector(), h.fine_operator.initialize_dof_vector()
+    h.fine_operator.rhs(b)
+    it, res = mgamd.solve_cg(h.fine_operator, h.mg, x, b, 1e-4)
+    assert it == itref
+    assert rel_err(x.to_host(), xref) < 1e-6  # inner CG stops on a tolerance: outer iterates agree to that level
+
+
+def test_size_independent_properties_at_scale(mgamd, ctx):
+    """quadrant L=6 p=4 (2.3 M DoFs) and hypercube L=6 p=1: symmetry, linearity, definiteness, constants -> only boundary rows."""
+    for geo, L, p in (("quadrant", 6, 4), ("hypercube", 6, 1), ("quadrant", 6, 1)):
+        t = mgamd.Triangulation(geo, L)
+        d = mgamd.DoFs(t, p)
+        op = mgamd.Operator(ctx, d)
+        n = d.n_dofs
+        rng = np.random.default_rng(8)
+        u, v = rng.standard_normal(n), rng.standard_normal(n)
+        vu, vv, Au, Av, Aw = (op.initialize_dof_vector() for _ in range(5))
+        vu.from_host(u), vv.from_host(v)
+        op.vmult(Au, vu), op.vmult(Av, vv)
+        assert vu.dot(Av) == pytest.approx(vv.dot(Au), rel=1e-11)  # symmetry
+        assert vu.dot(Au) > 0
+        w = op.initialize_dof_vector().from_host(2.0 * u - 3.0 * v)
+        op.vmult(Aw, w)
+        assert rel_err(Aw.to_host(), 2.0 * Au.to_host() - 3.0 * Av.to_host()) < 1e-13  # linearity
+        first_c = d.info.n_interior + d.info.n_tail
+        assert np.array_equal(Au.to_host()[first_c:], u[first_c:])  # identity rows (ref:include/operator.h:170-172)

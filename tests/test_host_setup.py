@@ -1,0 +1,168 @@
+"""CPU tests of the host logic behind the C ABI: meshes, DoF numbering, constraints, tables.
+The product's matrix-free formulation (parent-resolved indices + in-cell hanging-node interpolation)
+is emulated in numpy from the exported tables and compared with the oracle's assembled C^T K C."""
+import ctypes as C
+import re
+import os
+
+import numpy as np
+import pytest
+
+from conftest import oracle_level, ROOT
+
+CASES = [("quadrant", 3, 1, 0), ("quadrant", 3, 2, 0), ("quadrant", 3, 4, 0), ("quadrant", 4, 1, 0), ("quadrant", 3, 4, 1),
+         ("quadrant", 3, 3, 0), ("hypercube", 3, 1, 0), ("hypercube", 2, 4, 0), ("annulus", 5, 2, 0), ("circle", 4, 1, 0)]
+
+
+def test_c_abi_exports_every_declared_symbol(mgamd):
+    hdr = open(os.path.join(ROOT, "include", "mgamd.h")).read()
+    names = sorted(set(re.findall(r"\b(mgamd_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) > 40
+    missing = [n for n in names if not hasattr(mgamd._lib, n)]
+    assert not missing, missing
+
+
+def test_error_reporting(mgamd):
+    with pytest.raises(mgamd.MgamdError, match="not implemented"):
+        mgamd.Triangulation("torus", 2)
+    t = mgamd.Triangulation("hypercube", 1)
+    with pytest.raises(mgamd.MgamdError, match="degree"):
+        mgamd.DoFs(t, 0)
+
+
+def test_device_calls_fail_loudly_without_gpu(mgamd):
+    try:
+        import torch
+
+        have_gpu = torch.cuda.device_count() > 0
+    except Exception:
+        have_gpu = False
+    if have_gpu:
+        pytest.skip("GPU present")
+    with pytest.raises(mgamd.NoDeviceError):
+        mgamd.Context(0)
+
+
+def test_mesh_generators_match_oracle(mgamd, oracle):
+    for geo, L in (("quadrant", 4), ("quadrant", 5), ("annulus", 5), ("annulus", 6), ("circle", 5), ("hypercube", 3), ("quadrant", 0)):
+        t = mgamd.Triangulation(geo, L)
+        m = oracle.create_mesh(geo, L)
+        lev, i, j, k, mask = t.cells()
+        assert set(zip(lev.tolist(), i.tolist(), j.tolist(), k.tolist())) == m
+        assert [oracle.morton_key(c) for c in zip(lev.tolist(), i.tolist(), j.tolist(), k.tolist())] == sorted(oracle.morton_key(c) for c in m)
+        assert t.n_cells_hn == sum(oracle.is_cell_constrained(m, c) for c in m)
+    t = mgamd.Triangulation("quadrant_flexible", 2, 2)
+    assert t.n_cells == len(oracle.create_mesh("quadrant_flexible", 2, 2))
+
+
+def test_geometric_coarsening_sequence(mgamd, oracle):
+    for geo, L in (("quadrant", 5), ("annulus", 6), ("hypercube", 3)):
+        seq = mgamd.create_geometric_coarsening_sequence(mgamd.Triangulation(geo, L))
+        ref = oracle.coarsening_sequence(oracle.create_mesh(geo, L))
+        assert [t.n_cells for t in seq] == [len(m) for m in ref]
+        for t, m in zip(seq, ref):
+            lev, i, j, k, _ = t.cells()
+            assert set(zip(lev.tolist(), i.tolist(), j.tolist(), k.tolist())) == m
+
+
+def test_survey_appendix_b_counts(mgamd):
+    # quadrant p=4: L=4 50,553 ; L=5 321,243 DoFs, cells 701 / 4,712, n_hn 260 / 1,083
+    t4, t5 = mgamd.Triangulation("quadrant", 4), mgamd.Triangulation("quadrant", 5)
+    assert (t4.n_cells, t4.n_cells_hn, t5.n_cells, t5.n_cells_hn) == (701, 260, 4712, 1083)
+    assert mgamd.DoFs(t4, 4).n_dofs == 50553
+    assert mgamd.DoFs(t5, 4).n_dofs == 321243
+    assert mgamd.DoFs(t5, 1).n_dofs == 5703
+    assert mgamd.DoFs(t5, 2).n_dofs == 42467
+    a6 = mgamd.Triangulation("annulus", 6)
+    assert (a6.n_cells, a6.n_cells_hn, mgamd.DoFs(a6, 1).n_dofs, mgamd.DoFs(a6, 2).n_dofs) == (6840, 5360, 9763, 71509)
+
+
+def _interp(oracle, fe, mask, v, transpose):
+    p = fe.p
+    n = p + 1
+    if not (mask >> 3):
+        return v
+    v = v.reshape(n, n, n).copy()
+    cp = [mask & 1, (mask >> 1) & 1, (mask >> 2) & 1]
+    I = [oracle.lagrange_eval(fe.nodes, 0.5 * (fe.nodes + c))[0] for c in (0, 1)]
+    for d in ([0, 1, 2] if not transpose else [2, 1, 0]):
+        e, f = (d + 1) % 3, (d + 2) % 3
+        Ic = I[cp[d]].T if transpose else I[cp[d]]
+        for ae in range(n):
+            for af in range(n):
+                on_e, on_f = ae == cp[e] * p, af == cp[f] * p
+                if not (((mask >> (3 + e)) & 1 and on_e) or ((mask >> (3 + f)) & 1 and on_f) or ((mask >> (6 + d)) & 1 and on_e and on_f)):
+                    continue
+                idx = [None] * 3
+                idx[d], idx[e], idx[f] = slice(None), ae, af
+                sl = (idx[2], idx[1], idx[0])
+                v[sl] = Ic @ v[sl]
+    return v.ravel()
+
+
+@pytest.mark.parametrize("geo,L,p,max_brick", CASES)
+def test_tables_reproduce_assembled_operator(mgamd, oracle, geo, L, p, max_brick):
+    t = mgamd.Triangulation(geo, L)
+    d = mgamd.DoFs(t, p, max_brick)
+    lv = oracle_level(oracle, d, geo, L, p)
+    info = d.info
+    assert d.n_dofs == lv.n
+    first_c = info.n_interior + info.n_tail
+    assert not lv.constrained[:first_c].any() and lv.constrained[first_c:].all()
+    assert info.n_hanging == lv.hanging.sum() and info.n_dirichlet == (lv.dirichlet & ~lv.hanging).sum()
+    if max_brick == 1:
+        assert d.groups() == [(1, t.n_cells)]
+    # right-hand side (ref:include/operator.h:362-413)
+    assert np.abs(d.rhs_constant() - lv.rhs_constant).max() < 1e-15
+    # operator
+    cd = d.cell_dofs()
+    lev, _, _, _, mask = t.cells()
+    fe = lv.fe
+    Kc = np.kron(np.kron(fe.M, fe.M), fe.K) + np.kron(np.kron(fe.M, fe.K), fe.M) + np.kron(np.kron(fe.K, fe.M), fe.M)
+    x = np.random.default_rng(1).standard_normal(d.n_dofs)
+    y = np.zeros(d.n_dofs)
+    for ci in range(t.n_cells):
+        idx = cd[ci]
+        val = idx != mgamd.INVALID_DOF
+        g = np.where(val, x[np.where(val, idx, 0)], 0.0)
+        r = (2.0 / (1 << int(lev[ci]))) * (Kc @ _interp(oracle, fe, int(mask[ci]), g, False))
+        r = _interp(oracle, fe, int(mask[ci]), r, True)
+        np.add.at(y, idx[val], r[val])
+    y[first_c:] = x[first_c:]
+    ref = lv.A @ x
+    assert np.abs(y - ref).max() < 1e-13 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("geo,L,p,mg_type", [("quadrant", 3, 2, "HMG-global"), ("quadrant", 3, 4, "PMG"), ("annulus", 5, 1, "HMG-global")])
+def test_transfer_tables_reproduce_oracle_prolongation(mgamd, oracle, geo, L, p, mg_type):
+    fine_t = mgamd.Triangulation(geo, L)
+    if mg_type == "PMG":
+        tf, tc, pf, pc = fine_t, fine_t, p, p // 2
+        mf = mc = oracle.create_mesh(geo, L)
+    else:
+        tf, tc, pf, pc = fine_t, fine_t.coarsen(), p, p
+        mf = oracle.create_mesh(geo, L)
+        mc = oracle.coarsen_global(mf)
+    df, dc = mgamd.DoFs(tf, pf), mgamd.DoFs(tc, pc)
+    lf, lc = oracle.Level(mf, pf, df.keys()), oracle.Level(mc, pc, dc.keys())
+    P = oracle.build_transfer(lf, lc)
+    xc = np.random.default_rng(2).standard_normal(dc.n_dofs)
+    ref = P @ xc
+    fec = lc.fe
+    out = np.zeros(df.n_dofs)
+    for kind, nf, ci, cm, fi in mgamd.transfer_tables(df, dc):
+        if kind == 0:
+            E = np.eye(pc + 1)
+        elif kind == 1:
+            E = np.vstack([oracle.lagrange_eval(fec.nodes, 0.5 * fec.nodes)[0], oracle.lagrange_eval(fec.nodes, 0.5 + 0.5 * fec.nodes)[0][1:]])
+        else:
+            E = oracle.lagrange_eval(fec.nodes, oracle.gll_nodes(pf))[0]
+        E3 = np.kron(np.kron(E, E), E)
+        for n in range(ci.shape[0]):
+            val = ci[n] != mgamd.INVALID_DOF
+            g = np.where(val, xc[np.where(val, ci[n], 0)], 0.0)
+            v = E3 @ _interp(oracle, fec, int(cm[n]), g, False)
+            ok = fi[n] != mgamd.INVALID_DOF
+            assert not np.any(out[fi[n][ok]] != 0.0)  # every fine DoF owned by exactly one patch
+            out[fi[n][ok]] += v[ok]
+    assert np.abs(out - ref).max() < 1e-13 * max(np.abs(ref).max(), 1)
