@@ -1,0 +1,138 @@
+"""ORACLE (test infrastructure): ctypes wrapper of oracle/_build/libmgoracle_cpu.so, the C++/OpenMP CPU
+restatement of the hot path (oracle/cpu/mg_cpu_oracle.cpp).  PARITY UNPINNED, see mgoracle.py.
+It consumes the index tables exported by the product's host setup (validated against the independent
+numpy oracle in tests/test_host_setup.py) and redoes all arithmetic on the CPU in the reference's
+quadrature-based formulation.  Only tests/, smoke() and bench.py's cpu_baseline leg may import this."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libmgoracle_cpu.so")
+
+
+def _load():
+    if not os.path.exists(_SO):
+        subprocess.check_call(["make", "-C", _HERE])
+    lib = C.CDLL(_SO)
+    lib.mgo_level_create.restype = C.c_void_p
+    lib.mgo_transfer_create.restype = C.c_void_p
+    lib.mgo_mg_create.restype = C.c_void_p
+    lib.mgo_mg_max_eigenvalue.restype = C.c_double
+    lib.mgo_mg_time_vcycles.restype = C.c_double
+    return lib
+
+
+_lib = _load()
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def num_threads():
+    return _lib.mgo_num_threads()
+
+
+class CpuLevel:
+    def __init__(self, dofs):
+        """dofs: dealii_multigrid_amd.DoFs (only its exported tables are used)."""
+        self.p = dofs.degree
+        self.n = dofs.n_dofs
+        cd = np.ascontiguousarray(dofs.cell_dofs())
+        lev, _, _, _, mask = dofs.tria.cells()
+        first_c = dofs.info.n_interior + dofs.info.n_tail
+        self._h = C.c_void_p(
+            _lib.mgo_level_create(self.p, C.c_uint64(cd.shape[0]), C.c_uint32(self.n), C.c_uint32(first_c), _p(cd), _p(lev), _p(mask))
+        )
+
+    def vmult(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.zeros(self.n)
+        _lib.mgo_level_vmult(self._h, _p(y), _p(x))
+        return y
+
+    def inverse_diagonal(self):
+        d = np.zeros(self.n)
+        _lib.mgo_level_inverse_diagonal(self._h, _p(d))
+        return d
+
+    def n_colors(self):
+        return _lib.mgo_level_n_colors(self._h)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.mgo_level_destroy(self._h)
+            self._h = None
+
+
+class CpuTransfer:
+    def __init__(self, fine: CpuLevel, coarse: CpuLevel, tables):
+        """tables: dealii_multigrid_amd.transfer_tables(fine_dofs, coarse_dofs)."""
+        self.fine, self.coarse = fine, coarse
+        self._h = C.c_void_p(_lib.mgo_transfer_create(fine._h, coarse._h))
+        for kind, nf, ci, cm, fi in tables:
+            if ci.shape[0]:
+                _lib.mgo_transfer_set_group(
+                    self._h, kind, C.c_uint64(ci.shape[0]), nf, _p(np.ascontiguousarray(ci)), _p(np.ascontiguousarray(cm)), _p(np.ascontiguousarray(fi))
+                )
+
+    def prolongate_and_add(self, dst, src):
+        dst = np.ascontiguousarray(dst, dtype=np.float64).copy()
+        src = np.ascontiguousarray(src, dtype=np.float64)
+        _lib.mgo_transfer_prolongate_and_add(self._h, _p(dst), _p(src))
+        return dst
+
+    def restrict_and_add(self, dst, src):
+        dst = np.ascontiguousarray(dst, dtype=np.float64).copy()
+        src = np.ascontiguousarray(src, dtype=np.float64)
+        _lib.mgo_transfer_restrict_and_add(self._h, _p(dst), _p(src))
+        return dst
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.mgo_transfer_destroy(self._h)
+            self._h = None
+
+
+class CpuMultigrid:
+    def __init__(self, levels, transfers, smoother_degree=3, smoothing_range=20.0, eig_cg_n_iterations=20, coarse="direct"):
+        self.levels, self.transfers = levels, transfers
+        n = len(levels)
+        L = (C.c_void_p * n)(*[l._h for l in levels])
+        T = (C.c_void_p * n)(*[(t._h if t is not None else None) for t in transfers])
+        self._h = C.c_void_p(_lib.mgo_mg_create(n, L, T, smoother_degree, C.c_double(smoothing_range), eig_cg_n_iterations, coarse.encode()))
+
+    def max_eigenvalue(self, level):
+        return _lib.mgo_mg_max_eigenvalue(self._h, level)
+
+    def vcycle(self, r):
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        z = np.zeros_like(r)
+        _lib.mgo_mg_vcycle(self._h, _p(z), _p(r))
+        return z
+
+    def time_vcycles(self, r, n):
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        return _lib.mgo_mg_time_vcycles(self._h, _p(r), n)
+
+    def solve_cg(self, b, reltol=1e-4, abstol=1e-20, maxiter=10000):
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        x = np.zeros_like(b)
+        res = C.c_double()
+        it = _lib.mgo_solve_cg(self.levels[-1]._h, self._h, _p(x), _p(b), C.c_double(reltol), C.c_double(abstol), maxiter, C.byref(res))
+        return x, it, res.value
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.mgo_mg_destroy(self._h)
+            self._h = None
+
+
+def build_from_dofs(dofs_list, transfer_tables_fn, smoother_degree=3, coarse="direct"):
+    """dofs_list: product DoFs objects coarse -> fine; transfer_tables_fn(fine, coarse) -> tables."""
+    levels = [CpuLevel(d) for d in dofs_list]
+    transfers = [None] + [CpuTransfer(levels[l], levels[l - 1], transfer_tables_fn(dofs_list[l], dofs_list[l - 1])) for l in range(1, len(levels))]
+    return levels, transfers, CpuMultigrid(levels, transfers, smoother_degree, coarse=coarse)

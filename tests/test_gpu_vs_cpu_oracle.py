@@ -1,0 +1,40 @@
+"""GPU path against the C++ CPU oracle at sizes the numpy oracle cannot reach (10^5 - 10^6 DoFs):
+iteration counts equal, CG iterates agree to <= 1e-10 relative (north_star: stated FP64 tolerance)."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("geo,L,p,typ", [("quadrant", 5, 4, "HMG-global"), ("hypercube", 5, 1, "HMG-global"), ("quadrant", 6, 1, "HMG-global"),
+                                         ("annulus", 6, 2, "HMG-global"), ("annulus", 6, 4, "PMG"), ("hypercube", 4, 3, "HMG-global")])
+def test_solve_matches_cpu_oracle(mgamd, ctx, geo, L, p, typ):
+    import cpu_oracle
+
+    coarse = "amg" if typ == "HMG-global" else "cg_with_chebyshev"
+    h = mgamd.Hierarchy(ctx, geo, L, p, typ, coarse_solver=coarse)
+    levels, transfers, mg = cpu_oracle.build_from_dofs(h.dofs, mgamd.transfer_tables, coarse=coarse)
+    n = h.n_dofs
+    rng = np.random.default_rng(11)
+    # single operator application, every level
+    for l, op in enumerate(h.operators):
+        x = rng.standard_normal(h.dofs[l].n_dofs)
+        src, dst = op.initialize_dof_vector().from_host(x), op.initialize_dof_vector()
+        op.vmult(dst, src)
+        assert rel_err(dst.to_host(), levels[l].vmult(x)) < 1e-13
+        assert h.smoothers[l].eigenvalue_estimates()[1] == pytest.approx(mg.max_eigenvalue(l), rel=1e-9)
+    # one V-cycle
+    r = rng.standard_normal(n)
+    vr, vz = mgamd.Vector(ctx, n).from_host(r), mgamd.Vector(ctx, n)
+    h.mg.vmult(vz, vr)
+    tol_v = 1e-11 if coarse == "amg" else 1e-5
+    assert rel_err(vz.to_host(), mg.vcycle(r)) < tol_v
+    # full solve
+    b, x = h.fine_operator.initialize_dof_vector(), h.fine_operator.initialize_dof_vector()
+    h.fine_operator.rhs(b)
+    it, res = mgamd.solve_cg(h.fine_operator, h.mg, x, b, 1e-4)
+    xs, its, ress = mg.solve_cg(b.to_host(), 1e-4)
+    assert it == its
+    assert rel_err(x.to_host(), xs) < (1e-10 if coarse == "amg" else 1e-5)
