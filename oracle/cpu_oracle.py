@@ -13,7 +13,21 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libmgoracle_cpu.so")
 
 
+def _cpu_share():
+    """CPUs this process may really use: affinity mask and cgroup quota (the GPU box gives 16 of 128)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return n
+
+
 def _load():
+    if "OMP_NUM_THREADS" not in os.environ:
+        os.environ["OMP_NUM_THREADS"] = str(min(_cpu_share(), 16))  # gpurun box: 16 CPUs per GPU
     if not os.path.exists(_SO):
         subprocess.check_call(["make", "-C", _HERE])
     lib = C.CDLL(_SO)
