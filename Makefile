@@ -3,7 +3,8 @@ HIPCC      ?= /opt/rocm/bin/hipcc
 ARCH       ?= gfx950
 CSRC       := dealii_multigrid_amd/csrc
 LIBDIR     := dealii_multigrid_amd/lib
-HIPFLAGS   := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wall -Wno-unused-function -Iinclude
+DEBUGFLAGS ?=
+HIPFLAGS   := $(DEBUGFLAGS) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wall -Wno-unused-function -Iinclude
 LIB        := $(LIBDIR)/libmgamd.so
 HDRS       := $(wildcard $(CSRC)/*.hpp) include/mgamd.h
 

@@ -244,6 +244,15 @@ mgamd_level_op_rhs(mgamd_level_op *op, mgamd_vec *rhs)
 }
 
 int
+mgamd_level_op_debug_stamps(mgamd_level_op *op, unsigned long long *out, uint64_t max_count, uint64_t *count)
+{
+  MGAMD_TRY
+  REQUIRE(op && out && count);
+  *count = op->op->read_debug_stamps(out, max_count);
+  MGAMD_CATCH
+}
+
+int
 mgamd_cheb_create(mgamd_level_op *op, unsigned degree, double smoothing_range, unsigned eig_cg_n_iterations, mgamd_cheb **out)
 {
   MGAMD_TRY

@@ -44,6 +44,11 @@ namespace mgamd
     static constexpr int LINES   = N * N;
     static constexpr int SPW     = LINES >= 256 ? 1 : 256 / LINES;
     static constexpr int BLOCK   = ((SPW * LINES + 63) / 64) * 64;
+    // the operator kernel never uses more than 4 waves: two workgroups of 4 waves fit one CU with up to
+    // 256 VGPRs each, whereas two 5-wave workgroups need 4 waves on one SIMD (<= 128 VGPRs).  Lines beyond
+    // ABLOCK are handled in a second round by the first threads.
+    static constexpr int ABLOCK  = BLOCK > 256 ? 256 : BLOCK;
+    static constexpr int ROUNDS  = (SPW * LINES + ABLOCK - 1) / ABLOCK;
   };
 
   struct SlotGroupDev
@@ -121,68 +126,87 @@ namespace mgamd
           out[c * P + a] += T(Mc[a * (P + 1) + b]) * in[c * P + b];
   }
 
-  // The three sweeps.  Thread (sl, u, v) owns lattice line (u,v) of slot sl in every sweep.
+  // The three sweeps.  Line l = tid + r*BLOCK (r < ROUNDS) of the workgroup is (slot sl, u, v) in every sweep.
   // bufA holds the input and receives the result; bufB is scratch.  Ends with a barrier.
-  template <typename T, int P, int B>
+  template <typename T, int P, int B, int BLOCK>
   __device__ __forceinline__ void
-  lattice_sweeps(T *__restrict__ bufA, T *__restrict__ bufB, const Mats<P> &m, int sl, int u, int v, bool act, T h)
+  lattice_sweeps(T *__restrict__ bufA, T *__restrict__ bufB, const Mats<P> &m, int tid, int nslots, const double *__restrict__ hslot)
   {
-    constexpr int N  = Geo<P, B>::N;
-    constexpr int N3 = Geo<P, B>::N3;
+    using G              = Geo<P, B>;
+    constexpr int N      = G::N;
+    constexpr int N3     = G::N3;
+    constexpr int TOT    = G::SPW * G::LINES;
+    constexpr int ROUNDS = (TOT + BLOCK - 1) / BLOCK;
     T             r0[N], r1[N], r2[N];
-    // z sweep: thread = (x=u, y=v)
-    if (act)
+    // z sweep: line = (x=u, y=v)
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r)
       {
-        const int base = sl * N3 + v * N + u;
-#pragma unroll
-        for (int i = 0; i < N; ++i)
-          r0[i] = bufA[base + i * N * N];
-        line_mult<T, P, B>(m.M, r0, r1);
-        line_mult<T, P, B>(m.K, r0, r2);
-#pragma unroll
-        for (int i = 0; i < N; ++i)
+        const int l = tid + r * BLOCK, sl = l / G::LINES, ln = l % G::LINES, u = ln % N, v = ln / N;
+        if (l < TOT && sl < nslots)
           {
-            bufA[base + i * N * N] = r1[i];
-            bufB[base + i * N * N] = r2[i];
+            const int base = sl * N3 + v * N + u;
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              r0[i] = bufA[base + i * N * N];
+            line_mult<T, P, B>(m.M, r0, r1);
+            line_mult<T, P, B>(m.K, r0, r2);
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              {
+                bufA[base + i * N * N] = r1[i];
+                bufB[base + i * N * N] = r2[i];
+              }
           }
       }
     __syncthreads();
-    // y sweep: thread = (x=u, z=v):  c = My a ; g = Ky a + My b
-    if (act)
+    // y sweep: line = (x=u, z=v):  c = My a ; g = Ky a + My b
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r)
       {
-        const int base = sl * N3 + v * N * N + u;
-#pragma unroll
-        for (int i = 0; i < N; ++i)
-          r0[i] = bufA[base + i * N];
-        line_mult<T, P, B>(m.M, r0, r1);
-        line_mult<T, P, B>(m.K, r0, r2);
-#pragma unroll
-        for (int i = 0; i < N; ++i)
+        const int l = tid + r * BLOCK, sl = l / G::LINES, ln = l % G::LINES, u = ln % N, v = ln / N;
+        if (l < TOT && sl < nslots)
           {
-            bufA[base + i * N] = r1[i];
-            r0[i]              = bufB[base + i * N];
-          }
-        line_mult<T, P, B>(m.M, r0, r1);
+            const int base = sl * N3 + v * N * N + u;
 #pragma unroll
-        for (int i = 0; i < N; ++i)
-          bufB[base + i * N] = r1[i] + r2[i];
+            for (int i = 0; i < N; ++i)
+              r0[i] = bufA[base + i * N];
+            line_mult<T, P, B>(m.M, r0, r1);
+            line_mult<T, P, B>(m.K, r0, r2);
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              {
+                bufA[base + i * N] = r1[i];
+                r0[i]              = bufB[base + i * N];
+              }
+            line_mult<T, P, B>(m.M, r0, r1);
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              bufB[base + i * N] = r1[i] + r2[i];
+          }
       }
     __syncthreads();
-    // x sweep: thread = (y=u, z=v): out = h (Kx c + Mx g)
-    if (act)
+    // x sweep: line = (y=u, z=v): out = h (Kx c + Mx g)
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r)
       {
-        const int base = sl * N3 + (v * N + u) * N;
+        const int l = tid + r * BLOCK, sl = l / G::LINES, ln = l % G::LINES, u = ln % N, v = ln / N;
+        if (l < TOT && sl < nslots)
+          {
+            const T   h    = T(hslot[sl]);
+            const int base = sl * N3 + (v * N + u) * N;
 #pragma unroll
-        for (int i = 0; i < N; ++i)
-          r0[i] = bufA[base + i];
-        line_mult<T, P, B>(m.K, r0, r1);
+            for (int i = 0; i < N; ++i)
+              r0[i] = bufA[base + i];
+            line_mult<T, P, B>(m.K, r0, r1);
 #pragma unroll
-        for (int i = 0; i < N; ++i)
-          r0[i] = bufB[base + i];
-        line_mult<T, P, B>(m.M, r0, r2);
+            for (int i = 0; i < N; ++i)
+              r0[i] = bufB[base + i];
+            line_mult<T, P, B>(m.M, r0, r2);
 #pragma unroll
-        for (int i = 0; i < N; ++i)
-          bufA[base + i] = h * (r1[i] + r2[i]);
+            for (int i = 0; i < N; ++i)
+              bufA[base + i] = h * (r1[i] + r2[i]);
+          }
       }
     __syncthreads();
   }
@@ -264,59 +288,156 @@ namespace mgamd
     const T     *src;
     T           *tail_acc; // [n_tail] accumulators of shell partial sums
     uint32_t     n_interior;
+    unsigned long long *stamps; // debug only (MGAMD_STAMPS): 8 wall-clock stamps per workgroup, nullptr normally
+    uint32_t     ablate; // debug only (MGAMD_ABLATE): 1 no sweeps, 2 no shell atomics, 4 no interior epilogue, 8 no interior gather, 16 no shell gather
     Epilogue<T>  epi;
   };
 
-  // gather the slots of this workgroup into LDS
-  template <typename T, int P, int B>
-  __device__ __forceinline__ void
-  lattice_gather(T *__restrict__ bufA, const SlotGroupDev &g, const T *__restrict__ src, int slot0, int nslots, int tid)
+  // Interior-slot bookkeeping shared by the gather and the epilogue of lattice_apply_kernel: thread `tid`
+  // handles interior entries idx = tid + it*BLOCK, it < ITER, of the workgroup's slots.
+  template <int P, int B>
+  struct InteriorMap
   {
-    using G = Geo<P, B>;
-    if (G::N_INT > 0)
-      for (int idx = tid; idx < nslots * G::N_INT; idx += G::BLOCK)
-        {
-          const int sl = idx / (G::N_INT > 0 ? G::N_INT : 1), i = idx % (G::N_INT > 0 ? G::N_INT : 1);
-          const int x = i % (G::NI > 0 ? G::NI : 1), y = (i / (G::NI > 0 ? G::NI : 1)) % (G::NI > 0 ? G::NI : 1),
-                    z = i / (G::NI > 0 ? G::NI * G::NI : 1);
-          bufA[sl * G::N3 + ((z + 1) * G::N + (y + 1)) * G::N + x + 1] = src[g.interior_base[slot0 + sl] + i];
-        }
-    for (int idx = tid; idx < nslots * G::N_SHELL; idx += G::BLOCK)
-      {
-        const int      sl = idx / G::N_SHELL, s = idx % G::N_SHELL;
-        const uint32_t gi = g.shell_idx[(size_t)(slot0 + sl) * G::N_SHELL + s];
-        bufA[sl * G::N3 + g.shell_pos[s]] = gi != DEV_INVALID ? src[gi] : T(0);
-      }
-  }
+    using G                   = Geo<P, B>;
+    static constexpr int NI_  = G::NI > 0 ? G::NI : 1;
+    static constexpr int NIN_ = G::N_INT > 0 ? G::N_INT : 1;
+    static constexpr int ITER = (G::SPW * NIN_ + G::ABLOCK - 1) / G::ABLOCK;
+    __device__ static __forceinline__ void
+    decode(int idx, int nslots, bool &ok, int &sl, int &i, int &lds)
+    {
+      ok = idx < nslots * NIN_;
+      sl = (G::SPW == 1 || !ok) ? 0 : idx / NIN_;
+      i  = G::SPW == 1 ? (ok ? idx : 0) : (ok ? idx % NIN_ : 0);
+      const int x = i % NI_, y = (i / NI_) % NI_, z = i / (NI_ * NI_);
+      lds = sl * G::N3 + ((z + 1) * G::N + (y + 1)) * G::N + x + 1;
+    }
+  };
+
+  // K1: the level operator on the slots of one group.  All global loads of a phase are issued before the
+  // first dependent use (fully unrolled, branch-free clamped addresses): a rolled loop keeps ONE load per
+  // thread in flight and makes every phase latency-bound (measured 0.9 TB/s -> 3+ TB/s for the gather).
+  // K1: the level operator on the slots of one group.  All global loads of a phase are issued before the
+  // first dependent use (fully unrolled, branch-free clamped addresses): a rolled loop keeps ONE load per
+  // thread in flight and makes every phase latency-bound (measured 0.9 TB/s -> 3+ TB/s for the gather).
+  // The epilogue operands (x_old, b, D^-1) are requested BEFORE the sweeps so that their latency hides behind
+  // the arithmetic; the gathered x is kept in registers for the Chebyshev update instead of being re-read.
+#ifdef MGAMD_KERNEL_DEBUG
+#define MGAMD_STAMP(k)                         \
+  if (args.stamps && tid == 0)                 \
+    args.stamps[(size_t)blockIdx.x * 8 + (k)] = wall_clock64();
+#define MGAMD_ABLATED(bit) (args.ablate & (bit))
+#else
+#define MGAMD_STAMP(k)
+#define MGAMD_ABLATED(bit) false
+#endif
 
   template <typename T, int P, int B, int MODE>
   __global__ void
-  __launch_bounds__((Geo<P, B>::BLOCK)) lattice_apply_kernel(const ApplyArgs<T, P> args)
+  __launch_bounds__((Geo<P, B>::ABLOCK), (Geo<P, B>::ROUNDS > 1 ? 2 : 1)) lattice_apply_kernel(const ApplyArgs<T, P> args)
   {
-    using G = Geo<P, B>;
+    using G  = Geo<P, B>;
+    using IM = InteriorMap<P, B>;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     T *bufA = reinterpret_cast<T *>(smem_raw);
     T *bufB = bufA + G::SPW * G::N3;
 
+    constexpr int BLOCK = G::ABLOCK;
+    constexpr int ITER  = IM::ITER;
+    constexpr int ITERS = (G::SPW * G::N_SHELL + BLOCK - 1) / BLOCK;
+
     const int tid    = threadIdx.x;
     const int slot0  = blockIdx.x * G::SPW;
     const int nslots = min((int)G::SPW, (int)args.g.n_slots - slot0);
-    const int sl     = tid / G::LINES;
-    const int ln     = tid % G::LINES;
-    const int u = ln % G::N, v = ln / G::N;
-    const bool act = tid < G::SPW * G::LINES && sl < nslots;
+    MGAMD_STAMP(0)
 
-    lattice_gather<T, P, B>(bufA, args.g, args.src, slot0, nslots, tid);
-    __syncthreads();
-
-    uint32_t mask = 0;
-    T        h    = T(0);
-    if (act)
+    // ---- gather: addresses ----------------------------------------------------------------------------
+    uint32_t gbase[ITER]; // global index of interior entry `it` (always a valid address)
+    int      glds[ITER];  // its LDS position, -1 if this thread has no entry `it`
+    if (G::N_INT > 0)
       {
-        h = T(args.g.h[slot0 + sl]);
-        if (B == 1)
-          mask = args.g.mask[slot0 + sl];
+        const uint32_t base0 = args.g.interior_base[slot0];
+#pragma unroll
+        for (int it = 0; it < ITER; ++it)
+          {
+            bool ok;
+            int  s2, i, lds;
+            IM::decode(tid + it * BLOCK, nslots, ok, s2, i, lds);
+            gbase[it] = (G::SPW == 1 ? base0 : args.g.interior_base[slot0 + s2]) + i;
+            glds[it]  = ok ? lds : -1;
+          }
       }
+    uint32_t sgi[ITERS];
+    int      spos[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it)
+      {
+        const int  idx = tid + it * BLOCK;
+        const bool ok  = idx < nslots * G::N_SHELL;
+        const int  s2 = ok ? idx / G::N_SHELL : 0, s = idx % G::N_SHELL;
+        sgi[it]  = args.g.shell_idx[(size_t)(slot0 + s2) * G::N_SHELL + (ok ? s : 0)];
+        spos[it] = s2 * G::N3 + (int)args.g.shell_pos[s];
+        if (!ok)
+          spos[it] = -1;
+      }
+    // ---- gather: values ---------------------------------------------------------------------------------
+    T xg[ITER]; // gathered interior values, kept for the Chebyshev epilogue
+    if (G::N_INT > 0 && !MGAMD_ABLATED(8))
+      {
+#pragma unroll
+        for (int it = 0; it < ITER; ++it)
+          xg[it] = args.src[gbase[it]];
+      }
+    T sval[ITERS];
+    if (!MGAMD_ABLATED(16))
+      {
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it)
+          sval[it] = args.src[sgi[it] != DEV_INVALID ? sgi[it] : 0];
+      }
+    // ---- epilogue operands, requested now, consumed after the sweeps ----------------------------------------
+    T xo[ITER], bv[ITER], dv[ITER];
+    if (G::N_INT > 0 && !MGAMD_ABLATED(4))
+      {
+#pragma unroll
+        for (int it = 0; it < ITER; ++it)
+          {
+            xo[it] = bv[it] = dv[it] = T(0);
+            if (MODE == MODE_RESIDUAL)
+              bv[it] = args.epi.b[gbase[it]];
+            if (MODE == MODE_CHEB)
+              {
+                if (args.epi.xold)
+                  xo[it] = args.epi.xold[gbase[it]];
+                bv[it] = args.epi.b[gbase[it]];
+                dv[it] = args.epi.dinv[gbase[it]];
+              }
+          }
+      }
+    // ---- gather: into LDS -------------------------------------------------------------------------------
+    if (!MGAMD_ABLATED(16))
+      {
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it)
+          if (spos[it] >= 0)
+            bufA[spos[it]] = sgi[it] != DEV_INVALID ? sval[it] : T(0);
+      }
+    if (G::N_INT > 0 && !MGAMD_ABLATED(8))
+      {
+#pragma unroll
+        for (int it = 0; it < ITER; ++it)
+          if (glds[it] >= 0)
+            bufA[glds[it]] = xg[it];
+      }
+    __syncthreads();
+    MGAMD_STAMP(1)
+
+    // ---- hanging-node interpolation (single-cell slots only) ---------------------------------------------
+    const int sl = tid / G::LINES, ln = tid % G::LINES;
+    const int u = ln % G::N, v = ln / G::N;
+    const bool act  = tid < G::SPW * G::LINES && sl < nslots;
+    uint32_t   mask = 0;
+    if (B == 1 && act)
+      mask = args.g.mask[slot0 + sl];
     bool any_hanging = false;
     if (B == 1)
       {
@@ -325,30 +446,51 @@ namespace mgamd
           hanging_passes<T, P>(bufA, args.m, sl, u, v, act, mask, false);
       }
 
-    lattice_sweeps<T, P, B>(bufA, bufB, args.m, sl, u, v, act, h);
+    if (!MGAMD_ABLATED(1))
+      lattice_sweeps<T, P, B, BLOCK>(bufA, bufB, args.m, tid, nslots, args.g.h + slot0);
 
     if (B == 1 && any_hanging)
       hanging_passes<T, P>(bufA, args.m, sl, u, v, act, mask, true);
+    MGAMD_STAMP(2)
 
-    // interior DoFs are complete: fused epilogue, contiguous stores
-    if (G::N_INT > 0)
-      for (int idx = tid; idx < nslots * G::N_INT; idx += G::BLOCK)
-        {
-          const int sl2 = idx / (G::N_INT > 0 ? G::N_INT : 1), i = idx % (G::N_INT > 0 ? G::N_INT : 1);
-          const int x = i % (G::NI > 0 ? G::NI : 1), y = (i / (G::NI > 0 ? G::NI : 1)) % (G::NI > 0 ? G::NI : 1),
-                    z = i / (G::NI > 0 ? G::NI * G::NI : 1);
-          const T Ax = bufA[sl2 * G::N3 + ((z + 1) * G::N + (y + 1)) * G::N + x + 1];
-          apply_epilogue<T, MODE>(args.epi, args.g.interior_base[slot0 + sl2] + i, Ax);
-        }
-    // shell DoFs: partial sums into the tail accumulator
-    for (int idx = tid; idx < nslots * G::N_SHELL; idx += G::BLOCK)
+    // ---- interior DoFs are complete: fused epilogue, contiguous stores -----------------------------------
+    if (G::N_INT > 0 && !MGAMD_ABLATED(4))
       {
-        const int      sl2 = idx / G::N_SHELL, s = idx % G::N_SHELL;
-        const uint32_t gi  = args.g.shell_idx[(size_t)(slot0 + sl2) * G::N_SHELL + s];
-        if (gi != DEV_INVALID)
-          atomic_add(&args.tail_acc[gi - args.n_interior], bufA[sl2 * G::N3 + args.g.shell_pos[s]]);
+#pragma unroll
+        for (int it = 0; it < ITER; ++it)
+          if (glds[it] >= 0)
+            {
+              const T ax = bufA[glds[it]];
+              T       r;
+              if (MODE == MODE_VMULT)
+                r = ax;
+              else if (MODE == MODE_RESIDUAL)
+                r = bv[it] - ax;
+              else
+                r = xg[it] + args.epi.f1 * (xg[it] - xo[it]) + args.epi.f2 * dv[it] * (bv[it] - ax);
+              args.epi.out[gbase[it]] = r;
+            }
       }
+    MGAMD_STAMP(3)
+    // ---- shell DoFs: partial sums into the tail accumulator ------------------------------------------------
+    if (!MGAMD_ABLATED(2))
+      {
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it)
+          if (spos[it] >= 0 && sgi[it] != DEV_INVALID)
+            atomic_add(&args.tail_acc[sgi[it] - args.n_interior], bufA[spos[it]]);
+      }
+#ifdef MGAMD_KERNEL_DEBUG
+    if (args.stamps)
+      {
+        __builtin_amdgcn_s_waitcnt(0); // drain this wave's memory operations before the final stamp
+        __syncthreads();
+        MGAMD_STAMP(4)
+      }
+#endif
   }
+#undef MGAMD_STAMP
+#undef MGAMD_ABLATED
 
   // Diagonal of C^T K C.  Slots without hanging nodes: closed tensor form; single cells with hanging
   // faces/edges: one unit vector per local node through interpolation, sweeps and transpose.
@@ -424,7 +566,7 @@ namespace mgamd
                 bufA[idx] = (idx % G::N3) == j ? T(1) : T(0);
               __syncthreads();
               hanging_passes<T, P>(bufA, args.m, sl, u, v, act, mask, false);
-              lattice_sweeps<T, P, B>(bufA, bufB, args.m, sl, u, v, act, h);
+              lattice_sweeps<T, P, B, G::BLOCK>(bufA, bufB, args.m, tid, nslots, args.g.h + slot0);
               hanging_passes<T, P>(bufA, args.m, sl, u, v, act, mask, true);
               if (act && ln == 0 && (mask >> 3))
                 bufD[sl * G::N3 + j] = bufA[sl * G::N3 + j];
@@ -455,19 +597,52 @@ namespace mgamd
   __global__ void
   __launch_bounds__(256) tail_kernel(T *__restrict__ tail_acc, uint32_t n_interior, uint32_t n_tail, uint32_t n_rest, Epilogue<T> epi)
   {
+    constexpr int  U      = 4;
+    const uint32_t total  = n_tail + n_rest;
     const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_tail + n_rest; i += stride)
+    for (uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < total; i0 += U * stride)
       {
-        const uint32_t gi = n_interior + i;
-        T              Ax;
-        if (i < n_tail)
+        T ax[U], xv[U], xo[U], bv[U], dv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
           {
-            Ax          = tail_acc[i];
-            tail_acc[i] = T(0);
+            const uint32_t i  = i0 + u * stride;
+            const uint32_t gi = n_interior + i;
+            ax[u] = xv[u] = xo[u] = bv[u] = dv[u] = T(0);
+            if (i < total)
+              {
+                if (MODE != MODE_INVDIAG && (MODE == MODE_CHEB || i >= n_tail))
+                  xv[u] = epi.x[gi];
+                ax[u] = i < n_tail ? tail_acc[i] : xv[u];
+                if (MODE == MODE_RESIDUAL || MODE == MODE_CHEB)
+                  bv[u] = epi.b[gi];
+                if (MODE == MODE_CHEB)
+                  {
+                    if (epi.xold)
+                      xo[u] = epi.xold[gi];
+                    dv[u] = epi.dinv[gi];
+                  }
+              }
           }
-        else
-          Ax = (MODE == MODE_INVDIAG) ? T(0) : epi.x[gi];
-        apply_epilogue<T, MODE>(epi, gi, Ax);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          {
+            const uint32_t i  = i0 + u * stride;
+            const uint32_t gi = n_interior + i;
+            if (i < total)
+              {
+                if (i < n_tail)
+                  tail_acc[i] = T(0);
+                if (MODE == MODE_VMULT)
+                  epi.out[gi] = ax[u];
+                else if (MODE == MODE_RESIDUAL)
+                  epi.out[gi] = bv[u] - ax[u];
+                else if (MODE == MODE_CHEB)
+                  epi.out[gi] = xv[u] + epi.f1 * (xv[u] - xo[u]) + epi.f2 * dv[u] * (bv[u] - ax[u]);
+                else
+                  epi.out[gi] = (i < n_tail && fabs((double)ax[u]) > 1.0e-10) ? T(1) / ax[u] : T(1);
+              }
+          }
       }
   }
 

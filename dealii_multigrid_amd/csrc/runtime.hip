@@ -213,7 +213,7 @@ namespace mgamd
             HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             once = true;
           }
-        hipLaunchKernelGGL(kern, grid, G::BLOCK, lds, ctx->stream, a);
+        hipLaunchKernelGGL(kern, grid, G::ABLOCK, lds, ctx->stream, a);
       }
     HIP_CHECK(hipGetLastError());
   }
@@ -281,6 +281,9 @@ namespace mgamd
     std::vector<std::unique_ptr<GroupDev<T>>> groups;
     DBuf<T>                                   tail_acc;
     int                                       prof_B = 0; // brick size whose CHEB launches are profiled
+    uint32_t                                  ablate = 0; // debug: MGAMD_ABLATE
+    DBuf<unsigned long long>                  stamps;     // debug: MGAMD_STAMPS=<mode>, 8 stamps per workgroup of the largest group
+    int                                       stamp_mode = -1;
 
     LevelOperator(Ctx *c, const mgamd_dofs *dofs)
     {
@@ -314,6 +317,18 @@ namespace mgamd
             }
           groups.push_back(std::move(d));
         }
+      if (const char *e = getenv("MGAMD_ABLATE"))
+        ablate = (uint32_t)atoi(e);
+      if (const char *e = getenv("MGAMD_STAMPS"))
+        {
+          stamp_mode = atoi(e);
+          size_t nwg = 0;
+          for (auto &g : groups)
+            if (g->B == prof_B)
+              nwg = g->n_slots; // >= number of workgroups
+          stamps.alloc(nwg * 8 + 8);
+          stamps.zero(ctx->stream);
+        }
       tail_acc.alloc(std::max<uint32_t>(tables->n_tail, 1));
       tail_acc.zero(ctx->stream);
     }
@@ -343,12 +358,15 @@ namespace mgamd
       a.src        = src;
       a.tail_acc   = tail_acc.p;
       a.n_interior = tables->n_interior;
+      a.ablate     = ablate;
+      a.stamps     = nullptr;
       a.epi        = epi;
       for (auto &g : groups)
         {
           if (!g->n_slots)
             continue;
-          a.g = g->view();
+          a.g      = g->view();
+          a.stamps = (stamps.p && g->B == prof_B && MODE == stamp_mode && !diag) ? stamps.p : nullptr;
           const bool prof = ctx->profile && !diag && MODE == MODE_CHEB && g->B == prof_B && epi.xold != nullptr;
           if (prof)
             {
@@ -436,6 +454,16 @@ namespace mgamd
       if (dst.data == src.data)
         throw std::invalid_argument("vmult: dst and src must differ");
       vmult_raw(dst.as<T>(), src.as<T>());
+    }
+
+    size_t
+    read_debug_stamps(unsigned long long *out, size_t max_count) override
+    {
+      ctx->sync();
+      const size_t n = std::min(max_count, stamps.n);
+      if (n)
+        HIP_CHECK(hipMemcpy(out, stamps.p, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+      return n;
     }
 
     void
@@ -649,7 +677,7 @@ namespace mgamd
             }
         }
       if (cur != S)
-        HIP_CHECK(hipMemcpyAsync(S, cur, n * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
+        hipLaunchKernelGGL((vec_copy_kernel<T, T>), grid_for(n), 256, 0, ctx->stream, S, cur, n);
     }
 
     // general initial guess x0 in X; O is scratch; returns the buffer holding the result
@@ -688,7 +716,7 @@ namespace mgamd
         throw std::invalid_argument("PreconditionChebyshev::step: bad vectors");
       T *res = step_raw(dst.as<T>(), tmp.p, src.as<T>());
       if (res != dst.as<T>())
-        HIP_CHECK(hipMemcpyAsync(dst.data, res, dst.n * sizeof(T), hipMemcpyDeviceToDevice, lop->ctx->stream));
+        hipLaunchKernelGGL((vec_copy_kernel<T, T>), grid_for(dst.n), 256, 0, lop->ctx->stream, dst.as<T>(), res, dst.n);
     }
   };
 
@@ -876,6 +904,10 @@ namespace mgamd
     std::vector<Chebyshev<T> *>      sm;
     std::vector<std::unique_ptr<DBuf<T>>> defect, S, Tb, res;
     std::vector<T *>                 sol; // where the level solution currently lives
+    // per-cycle views of the finest level: when the outer vectors have the level number type, r IS the
+    // finest defect and z is one of the two smoother buffers (no copy_to_mg / copy_from_mg traffic)
+    std::vector<const T *> dview;
+    std::vector<T *>       sview, tview;
     std::string                      coarse_type;
     DBuf<double>                     coarse_inv; // dense inverse for "direct"
     DBuf<T>                          cg_r, cg_z, cg_p, cg_Ap;
@@ -911,6 +943,15 @@ namespace mgamd
           res[l]->alloc(n);
         }
       sol.assign(nl, nullptr);
+      dview.assign(nl, nullptr);
+      sview.assign(nl, nullptr);
+      tview.assign(nl, nullptr);
+      for (unsigned l = 0; l < nl; ++l)
+        {
+          dview[l] = defect[l]->p;
+          sview[l] = S[l]->p;
+          tview[l] = Tb[l]->p;
+        }
       coarse_type = coarse;
       if (coarse == "amg" || coarse == "cg_with_amg" || coarse == "amg_petsc")
         coarse_type = "direct"; // 1-cell coarse level: ML/BoomerAMG degenerate to a direct solve
@@ -1067,22 +1108,22 @@ namespace mgamd
           return;
         }
       stage(0, true, l);
-      sm[l]->vmult_raw(S[l]->p, Tb[l]->p, defect[l]->p); // pre-smoothing, zero start
+      sm[l]->vmult_raw(sview[l], tview[l], dview[l]); // pre-smoothing, zero start
       stage(0, false, l);
       stage(1, true, l);
-      ops[l]->residual_raw(res[l]->p, defect[l]->p, S[l]->p); // t = d - A x
+      ops[l]->residual_raw(res[l]->p, dview[l], sview[l]); // t = d - A x
       stage(1, false, l);
       stage(2, true, l);
       tr[l]->restrict_raw(defect[l - 1]->p, res[l]->p);
       stage(2, false, l);
       level_v_step(l - 1);
       stage(4, true, l);
-      tr[l]->prolongate_raw(S[l]->p, sol[l - 1]);
+      tr[l]->prolongate_raw(sview[l], sol[l - 1]);
       stage(4, false, l);
       stage(5, true, l); // edge_prolongation: no-op for global coarsening (ref:multigrid_throughput.cc:1126-1130)
       stage(5, false, l);
       stage(6, true, l);
-      sol[l] = sm[l]->step_raw(S[l]->p, Tb[l]->p, defect[l]->p); // post-smoothing
+      sol[l] = sm[l]->step_raw(sview[l], tview[l], dview[l]); // post-smoothing
       stage(6, false, l);
     }
 
@@ -1090,38 +1131,60 @@ namespace mgamd
     void
     vcycle_raw(TO *z, const TO *r)
     {
-      const size_t n = ops[nl - 1]->n_dofs();
+      const size_t   n    = ops[nl - 1]->n_dofs();
+      const unsigned L    = nl - 1;
+      const bool     same = sizeof(TO) == sizeof(T) && nl > 1;
       // copy_to_mg: defect_L = cast(r), coarser defects zero
       if (cb)
         {
           ctx->sync();
-          cb(7, 1, nl - 1, cb_user);
+          cb(7, 1, L, cb_user);
         }
-      if (sizeof(TO) == sizeof(T))
-        HIP_CHECK(hipMemcpyAsync(defect[nl - 1]->p, r, n * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
+      if (same)
+        {
+          // r is the finest defect; z takes the role of the smoother buffer the post-smoother ends in
+          // (Chebyshev::step_raw returns its second buffer for odd degree, the first for even degree)
+          dview[L] = reinterpret_cast<const T *>(r);
+          if (sm[L]->degree % 2 == 1)
+            {
+              sview[L] = S[L]->p;
+              tview[L] = reinterpret_cast<T *>(z);
+            }
+          else
+            {
+              sview[L] = reinterpret_cast<T *>(z);
+              tview[L] = S[L]->p;
+            }
+        }
       else
-        hipLaunchKernelGGL((vec_copy_kernel<T, TO>), grid_for(n), 256, 0, ctx->stream, defect[nl - 1]->p, r, n);
+        {
+          dview[L] = defect[L]->p;
+          sview[L] = S[L]->p;
+          tview[L] = Tb[L]->p;
+          if (sizeof(TO) == sizeof(T))
+            hipLaunchKernelGGL((vec_copy_kernel<T, TO>), grid_for(n), 256, 0, ctx->stream, defect[L]->p, r, n);
+          else
+            hipLaunchKernelGGL((vec_copy_kernel<T, TO>), grid_for(n), 256, 0, ctx->stream, defect[L]->p, r, n);
+        }
       for (unsigned l = 0; l + 1 < nl; ++l)
         defect[l]->zero(ctx->stream);
       if (cb)
         {
           ctx->sync();
-          cb(7, 0, nl - 1, cb_user);
+          cb(7, 0, L, cb_user);
         }
-      level_v_step(nl - 1);
+      level_v_step(L);
       if (cb)
         {
           ctx->sync();
-          cb(8, 1, nl - 1, cb_user);
+          cb(8, 1, L, cb_user);
         }
-      if (sizeof(TO) == sizeof(T))
-        HIP_CHECK(hipMemcpyAsync(z, sol[nl - 1], n * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
-      else
-        hipLaunchKernelGGL((vec_copy_kernel<TO, T>), grid_for(n), 256, 0, ctx->stream, z, sol[nl - 1], n);
+      if ((const void *)sol[L] != (const void *)z)
+        hipLaunchKernelGGL((vec_copy_kernel<TO, T>), grid_for(n), 256, 0, ctx->stream, z, sol[L], n);
       if (cb)
         {
           ctx->sync();
-          cb(8, 0, nl - 1, cb_user);
+          cb(8, 0, L, cb_user);
         }
     }
 

@@ -160,6 +160,8 @@ namespace mgamd
     vmult(mgamd_vec &dst, const mgamd_vec &src) = 0;
     virtual void
     compute_inverse_diagonal(mgamd_vec &d) = 0;
+    virtual size_t
+    read_debug_stamps(unsigned long long *out, size_t max_count) = 0;
     void
     rhs(mgamd_vec &b);
   };

@@ -135,6 +135,10 @@ int mgamd_level_op_inverse_diagonal(mgamd_level_op *op, mgamd_vec *diagonal);
 /* Operator::rhs with f == 1, g == 0 (ref:include/operator.h:362-447) */
 int mgamd_level_op_rhs(mgamd_level_op *op, mgamd_vec *rhs);
 
+/* development aid: with MGAMD_STAMPS=<mode> in the environment the largest slot group's kernel of that mode
+ * records 8 wall-clock stamps (10 ns ticks) per workgroup at its phase boundaries; returns them */
+int mgamd_level_op_debug_stamps(mgamd_level_op *op, unsigned long long *out, uint64_t max_count, uint64_t *count);
+
 /* PreconditionChebyshev (ref:multigrid_throughput.cc:849-852, 867-883): the inverse diagonal is
  * computed internally (DiagonalMatrix preconditioner); eigenvalues are estimated at creation with
  * eig_cg_n_iterations CG steps, max *= 1.2, min = max / smoothing_range. */
