@@ -8,7 +8,9 @@ HIPFLAGS   := $(DEBUGFLAGS) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -munsafe
 LIB        := $(LIBDIR)/libmgamd.so
 HDRS       := $(wildcard $(CSRC)/*.hpp) include/mgamd.h
 
-all: $(LIB) oracle
+BIN        := dealii_multigrid_amd/bin/multigrid_throughput
+
+all: $(LIB) $(BIN) oracle
 
 $(LIBDIR)/runtime.o: $(CSRC)/runtime.hip $(HDRS)
 	@mkdir -p $(LIBDIR)
@@ -24,6 +26,10 @@ $(LIBDIR)/c_api_host.o: $(CSRC)/c_api_host.cpp $(HDRS)
 
 $(LIB): $(LIBDIR)/runtime.o $(LIBDIR)/c_api_device.o $(LIBDIR)/c_api_host.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
+
+$(BIN): dealii_multigrid_amd/harness/multigrid_throughput.cpp $(CSRC)/mgamd.hpp include/mgamd.h $(LIB)
+	@mkdir -p dealii_multigrid_amd/bin
+	g++ -O2 -std=c++17 -Wall -Iinclude $< -o $@ -L$(LIBDIR) -lmgamd -Wl,-rpath,'$$ORIGIN/../lib'
 
 oracle:
 	$(MAKE) -C oracle

@@ -67,6 +67,20 @@ def run_workload(m, ctx, geometry, n_ref, degree, steps, warmup, barrier, sync, 
     return res
 
 
+def pmc_traffic(n_ref, B):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary of this workload
+    (profiles/*_pmc_traffic_octant<nref>_p4.json, made by tools/pmc_summary.py: FETCH_SIZE x2 + WRITE_SIZE, separate
+    passes), averaged over the kernel's launches like `achieved`; None when no profile of this workload is committed."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_traffic_octant{n_ref}_p4.json")))
+    if not files:
+        return None
+    rows = [r for r in json.load(open(files[-1]))["kernels"] if f"lattice_apply_kernel<double, 4, {B}, 2>" in r["kernel"]]
+    n = sum(r["launches"] for r in rows)
+    return sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows) / n if n else None
+
+
 def cpu_baseline(m, geometry, n_ref, degree, max_seconds=25.0):
     """host-CPU baseline: the C++/OpenMP oracle ("port": deal.II cannot be built here) on a bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -158,7 +172,7 @@ def main():
         achieved = by / (ms * 1e-3) / 1e9
         B = max(prim["groups"], key=lambda g: g[1] * (4 * g[0] + 1) ** 3)[0]
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                           "traffic": None,
+                           "traffic": pmc_traffic(args.nref, B),
                            "kernel": f"lattice_apply_kernel<double,4,{B},MODE_CHEB> (Chebyshev pass with x_old: 5 words/DoF)",
                            "launches": n, "avg_launch_us": ms / n * 1e3, "algorithmic_bytes_per_launch": by / n}
     if rank == 0 and not args.no_secondary:

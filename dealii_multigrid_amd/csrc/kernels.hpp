@@ -673,6 +673,31 @@ namespace mgamd
     T              *dst;
   };
 
+  // dst[owned fine DoFs] += buf  (every fine DoF has exactly one owning patch: plain read-modify-write);
+  // all index loads, then all value loads, then the stores
+  template <typename T, int PC, int NF>
+  __device__ __forceinline__ void
+  fine_rmw(const TransferArgs<T, PC, NF> &args, const T *__restrict__ buf, int p0, int np, int tid)
+  {
+    using G           = TransferGeo<PC, NF>;
+    constexpr int ITF = (G::SPW * G::NF3 + G::BLOCK - 1) / G::BLOCK;
+    uint32_t      gi[ITF];
+    T             val[ITF];
+#pragma unroll
+    for (int it = 0; it < ITF; ++it)
+      {
+        const int idx = tid + it * G::BLOCK;
+        gi[it]        = idx < np * G::NF3 ? args.fine_idx[(size_t)p0 * G::NF3 + idx] : DEV_INVALID;
+      }
+#pragma unroll
+    for (int it = 0; it < ITF; ++it)
+      val[it] = args.dst[gi[it] != DEV_INVALID ? gi[it] : 0];
+#pragma unroll
+    for (int it = 0; it < ITF; ++it)
+      if (gi[it] != DEV_INVALID)
+        args.dst[gi[it]] = val[it] + buf[tid + it * G::BLOCK];
+  }
+
   // x_f[owned fine DoFs] += E (x) E (x) E  (C_cell x_c)
   template <typename T, int PC, int NF, bool IDENTITY>
   __global__ void
@@ -691,13 +716,28 @@ namespace mgamd
     const int u = ln % NF, v = ln / NF;
     const bool act = tid < G::SPW * G::LINES && sl < np;
 
-    // gather coarse values into bufB (stride NC3 per patch)
-    for (int idx = tid; idx < np * G::NC3; idx += G::BLOCK)
-      {
-        const int      s  = idx / G::NC3, i = idx % G::NC3;
-        const uint32_t gi = args.coarse_idx[(size_t)(p0 + s) * G::NC3 + i];
-        bufB[s * G::NF3 + i] = gi != DEV_INVALID ? args.src[gi] : T(0);
-      }
+    // gather coarse values into bufB (stride NF3 per patch); loads batched: indices, then values, then LDS
+    {
+      constexpr int ITC = (G::SPW * G::NC3 + G::BLOCK - 1) / G::BLOCK;
+      uint32_t      gi[ITC];
+      T             val[ITC];
+#pragma unroll
+      for (int it = 0; it < ITC; ++it)
+        {
+          const int idx = tid + it * G::BLOCK;
+          gi[it]        = idx < np * G::NC3 ? args.coarse_idx[(size_t)p0 * G::NC3 + idx] : DEV_INVALID;
+        }
+#pragma unroll
+      for (int it = 0; it < ITC; ++it)
+        val[it] = args.src[gi[it] != DEV_INVALID ? gi[it] : 0];
+#pragma unroll
+      for (int it = 0; it < ITC; ++it)
+        {
+          const int idx = tid + it * G::BLOCK;
+          if (idx < np * G::NC3)
+            bufB[(idx / G::NC3) * G::NF3 + idx % G::NC3] = gi[it] != DEV_INVALID ? val[it] : T(0);
+        }
+    }
     __syncthreads();
     uint32_t mask = 0;
     if (act)
@@ -713,13 +753,7 @@ namespace mgamd
       }
     if (IDENTITY)
       {
-        for (int idx = tid; idx < np * G::NF3; idx += G::BLOCK)
-          {
-            const int      s  = idx / G::NF3, i = idx % G::NF3;
-            const uint32_t gi = args.fine_idx[(size_t)(p0 + s) * G::NF3 + i];
-            if (gi != DEV_INVALID)
-              args.dst[gi] += bufB[s * G::NF3 + i];
-          }
+        fine_rmw<T, PC, NF>(args, bufB, p0, np, tid);
         return;
       }
     // x: (NC,NC,NC) -> (NC,NC,NF); thread (u,v) = (y,z) < NC
@@ -776,13 +810,7 @@ namespace mgamd
           }
       }
     __syncthreads();
-    for (int idx = tid; idx < np * G::NF3; idx += G::BLOCK)
-      {
-        const int      s  = idx / G::NF3, i = idx % G::NF3;
-        const uint32_t gi = args.fine_idx[(size_t)(p0 + s) * G::NF3 + i];
-        if (gi != DEV_INVALID)
-          args.dst[gi] += bufA[s * G::NF3 + i];
-      }
+    fine_rmw<T, PC, NF>(args, bufA, p0, np, tid);
   }
 
   // d_c += C_cell^T (E (x) E (x) E)^T r_f[owned fine DoFs]
@@ -803,12 +831,27 @@ namespace mgamd
     const int u = ln % NF, v = ln / NF;
     const bool act = tid < G::SPW * G::LINES && sl < np;
 
-    for (int idx = tid; idx < np * G::NF3; idx += G::BLOCK)
-      {
-        const int      s  = idx / G::NF3, i = idx % G::NF3;
-        const uint32_t gi = args.fine_idx[(size_t)(p0 + s) * G::NF3 + i];
-        bufA[s * G::NF3 + i] = gi != DEV_INVALID ? args.src[gi] : T(0);
-      }
+    {
+      constexpr int ITF = (G::SPW * G::NF3 + G::BLOCK - 1) / G::BLOCK;
+      uint32_t      gi[ITF];
+      T             val[ITF];
+#pragma unroll
+      for (int it = 0; it < ITF; ++it)
+        {
+          const int idx = tid + it * G::BLOCK;
+          gi[it]        = idx < np * G::NF3 ? args.fine_idx[(size_t)p0 * G::NF3 + idx] : DEV_INVALID;
+        }
+#pragma unroll
+      for (int it = 0; it < ITF; ++it)
+        val[it] = args.src[gi[it] != DEV_INVALID ? gi[it] : 0];
+#pragma unroll
+      for (int it = 0; it < ITF; ++it)
+        {
+          const int idx = tid + it * G::BLOCK;
+          if (idx < G::SPW * G::NF3)
+            bufA[idx] = gi[it] != DEV_INVALID ? val[it] : T(0);
+        }
+    }
     __syncthreads();
     if (!IDENTITY)
       {
@@ -878,13 +921,23 @@ namespace mgamd
         const bool la   = act && u < G::NC && v < G::NC;
         hanging_passes<T, PC>(view, args.m, sl, u, v, la, la ? mask : 0u, true);
       }
-    for (int idx = tid; idx < np * G::NC3; idx += G::BLOCK)
-      {
-        const int      s  = idx / G::NC3, i = idx % G::NC3;
-        const uint32_t gi = args.coarse_idx[(size_t)(p0 + s) * G::NC3 + i];
-        if (gi != DEV_INVALID)
-          atomic_add(&args.dst[gi], res[s * G::NF3 + i]);
-      }
+    {
+      constexpr int ITC = (G::SPW * G::NC3 + G::BLOCK - 1) / G::BLOCK;
+      uint32_t      gi[ITC];
+#pragma unroll
+      for (int it = 0; it < ITC; ++it)
+        {
+          const int idx = tid + it * G::BLOCK;
+          gi[it]        = idx < np * G::NC3 ? args.coarse_idx[(size_t)p0 * G::NC3 + idx] : DEV_INVALID;
+        }
+#pragma unroll
+      for (int it = 0; it < ITC; ++it)
+        if (gi[it] != DEV_INVALID)
+          {
+            const int idx = tid + it * G::BLOCK;
+            atomic_add(&args.dst[gi[it]], res[(idx / G::NC3) * G::NF3 + idx % G::NC3]);
+          }
+    }
   }
 
   // ------------------------------------------------------------------------------------------

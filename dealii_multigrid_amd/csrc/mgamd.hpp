@@ -1,0 +1,513 @@
+// mgamd.hpp -- header-only C++ layer over the C ABI (include/mgamd.h) that re-exposes the MI355X path with
+// the class and method names deal.II gives it in the reference, so that code written like
+// ref:multigrid_throughput.cc:817-1666 (mg_solve / solve_with_global_coarsening) compiles against it:
+//
+//   mgamd::Triangulation          <-> parallel::distributed::Triangulation<3> + GridGenerator::create_*
+//   mgamd::DoFHandler             <-> DoFHandler<3> + AffineConstraints + MatrixFree::reinit
+//   mgamd::Vector                 <-> LinearAlgebra::distributed::Vector<Number>
+//   mgamd::Operator               <-> Operator<3,1,Number>                 (ref:include/operator.h:11-557)
+//   mgamd::PreconditionChebyshev  <-> PreconditionChebyshev<Operator,Vector,DiagonalMatrix<Vector>>
+//   mgamd::MGTwoLevelTransfer     <-> MGTwoLevelTransfer<3,Vector>
+//   mgamd::PreconditionMG         <-> Multigrid<Vector> + PreconditionMG + MGTransferGlobalCoarsening
+//   mgamd::SolverCG / ReductionControl
+//
+// Status codes become exceptions (std::runtime_error), as AssertThrow does in the reference
+// (ref:multigrid_throughput.cc:2444-2468 catches them in main).
+#pragma once
+#include "../../include/mgamd.h"
+
+#include <functional>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace mgamd
+{
+  inline void
+  check(int status)
+  {
+    if (status != MGAMD_OK)
+      throw std::runtime_error(mgamd_last_error());
+  }
+
+  class Triangulation
+  {
+  public:
+    Triangulation(const std::string &geometry_type, unsigned n_ref_global, unsigned n_ref_local = 0)
+    {
+      mgamd_tria *t = nullptr;
+      check(mgamd_tria_create(geometry_type.c_str(), n_ref_global, n_ref_local, &t));
+      h.reset(t, mgamd_tria_destroy);
+      query();
+    }
+    // one step of MGTransferGlobalCoarseningTools::create_geometric_coarsening_sequence
+    std::shared_ptr<Triangulation>
+    coarsen() const
+    {
+      mgamd_tria *t = nullptr;
+      check(mgamd_tria_coarsen(h.get(), &t));
+      auto r = std::shared_ptr<Triangulation>(new Triangulation());
+      r->h.reset(t, mgamd_tria_destroy);
+      r->query();
+      return r;
+    }
+    uint64_t
+    n_global_active_cells() const
+    {
+      return n_cells;
+    }
+    unsigned
+    n_global_levels() const
+    {
+      return n_levels;
+    }
+    uint64_t
+    n_cells_with_hanging_nodes() const
+    {
+      return n_cells_hn;
+    }
+    mgamd_tria *
+    get() const
+    {
+      return h.get();
+    }
+
+  private:
+    Triangulation() = default;
+    void
+    query()
+    {
+      check(mgamd_tria_info(h.get(), &n_cells, &n_levels, &n_cells_hn));
+    }
+    std::shared_ptr<mgamd_tria> h;
+    uint64_t                    n_cells = 0, n_cells_hn = 0;
+    uint32_t                    n_levels = 0;
+  };
+
+  // MGTransferGlobalCoarseningTools::create_geometric_coarsening_sequence (ref:multigrid_throughput.cc:2219-2224)
+  inline std::vector<std::shared_ptr<const Triangulation>>
+  create_geometric_coarsening_sequence(const std::shared_ptr<const Triangulation> &fine)
+  {
+    std::vector<std::shared_ptr<const Triangulation>> seq{fine};
+    while (seq.back()->n_global_active_cells() > 1)
+      seq.push_back(seq.back()->coarsen());
+    return {seq.rbegin(), seq.rend()};
+  }
+
+  // ...::create_polynomial_coarsening_sequence(degree, bisect) (ref:multigrid_throughput.cc:1506-1510)
+  inline std::vector<unsigned>
+  create_polynomial_coarsening_sequence(unsigned degree)
+  {
+    std::vector<unsigned> seq{degree};
+    while (seq.back() > 1)
+      seq.push_back(std::max(seq.back() / 2, 1u));
+    return {seq.rbegin(), seq.rend()};
+  }
+
+  class DoFHandler
+  {
+  public:
+    DoFHandler(const std::shared_ptr<const Triangulation> &tria, unsigned fe_degree)
+      : tria(tria)
+    {
+      mgamd_dofs *d = nullptr;
+      check(mgamd_dofs_create(tria->get(), (int)fe_degree, 0, &d));
+      h.reset(d, mgamd_dofs_destroy);
+      check(mgamd_dofs_info(h.get(), &info));
+    }
+    uint64_t
+    n_dofs() const
+    {
+      return info.n_dofs;
+    }
+    const Triangulation &
+    get_triangulation() const
+    {
+      return *tria;
+    }
+    mgamd_dofs *
+    get() const
+    {
+      return h.get();
+    }
+    mgamd_dofs_info_t info;
+
+  private:
+    std::shared_ptr<const Triangulation> tria;
+    std::shared_ptr<mgamd_dofs>          h;
+  };
+
+  class Context
+  {
+  public:
+    explicit Context(int device = 0)
+    {
+      mgamd_ctx *c = nullptr;
+      check(mgamd_ctx_create(device, &c));
+      h.reset(c, mgamd_ctx_destroy);
+    }
+    void
+    synchronize() const
+    {
+      check(mgamd_ctx_synchronize(h.get()));
+    }
+    mgamd_ctx *
+    get() const
+    {
+      return h.get();
+    }
+
+  private:
+    std::shared_ptr<mgamd_ctx> h;
+  };
+
+  class Vector
+  {
+  public:
+    Vector() = default;
+    explicit Vector(mgamd_vec *v)
+    {
+      h.reset(v, mgamd_vec_destroy);
+    }
+    Vector(const Context &ctx, uint64_t n, int number_type = MGAMD_F64)
+    {
+      mgamd_vec *v = nullptr;
+      check(mgamd_vec_create(ctx.get(), n, number_type, &v));
+      h.reset(v, mgamd_vec_destroy);
+    }
+    uint64_t
+    size() const
+    {
+      uint64_t n = 0;
+      check(mgamd_vec_size(h.get(), &n));
+      return n;
+    }
+    Vector &
+    operator=(double value)
+    {
+      check(mgamd_vec_set(h.get(), value));
+      return *this;
+    }
+    void
+    sadd(double s, double a, const Vector &x)
+    {
+      check(mgamd_vec_sadd(h.get(), s, a, x.get()));
+    }
+    void
+    add(double a, const Vector &x)
+    {
+      check(mgamd_vec_axpy(h.get(), a, x.get()));
+    }
+    double
+    operator*(const Vector &other) const
+    {
+      double r = 0;
+      check(mgamd_vec_dot(h.get(), other.get(), &r));
+      return r;
+    }
+    double
+    l2_norm() const
+    {
+      double r = 0;
+      check(mgamd_vec_norm2(h.get(), &r));
+      return r;
+    }
+    void
+    copy_from_host(const std::vector<double> &v)
+    {
+      check(mgamd_vec_from_host(h.get(), v.data()));
+    }
+    std::vector<double>
+    copy_to_host() const
+    {
+      std::vector<double> v(size());
+      check(mgamd_vec_to_host(h.get(), v.data()));
+      return v;
+    }
+    mgamd_vec *
+    get() const
+    {
+      return h.get();
+    }
+
+  private:
+    std::shared_ptr<mgamd_vec> h;
+  };
+
+  // Operator<dim=3, n_components=1, Number> (ref:include/operator.h:11)
+  class Operator
+  {
+  public:
+    using VectorType = Vector;
+    // Operator::reinit(mapping, dof_handler, quad, constraints) (ref:include/operator.h:24-47): mapping is
+    // MappingQ1 on cubes, the quadrature QGauss(degree+1), constraints zero Dirichlet + hanging nodes.
+    void
+    reinit(const Context &ctx, const DoFHandler &dof_handler, int number_type = MGAMD_F64)
+    {
+      mgamd_level_op *o = nullptr;
+      check(mgamd_level_op_create(ctx.get(), dof_handler.get(), number_type, &o));
+      h.reset(o, mgamd_level_op_destroy);
+    }
+    uint64_t
+    m() const
+    {
+      uint64_t n = 0;
+      check(mgamd_level_op_m(h.get(), &n));
+      return n;
+    }
+    void
+    initialize_dof_vector(Vector &vec) const
+    {
+      mgamd_vec *v = nullptr;
+      check(mgamd_level_op_init_vector(h.get(), &v));
+      vec = Vector(v);
+    }
+    void
+    vmult(Vector &dst, const Vector &src) const
+    {
+      check(mgamd_level_op_vmult(h.get(), dst.get(), src.get()));
+    }
+    void
+    Tvmult(Vector &dst, const Vector &src) const
+    {
+      vmult(dst, src); // ref:include/operator.h:185-189
+    }
+    void
+    compute_inverse_diagonal(Vector &diagonal) const
+    {
+      if (!diagonal.get())
+        initialize_dof_vector(diagonal);
+      check(mgamd_level_op_inverse_diagonal(h.get(), diagonal.get()));
+    }
+    void
+    rhs(Vector &system_rhs) const
+    {
+      check(mgamd_level_op_rhs(h.get(), system_rhs.get()));
+    }
+    mgamd_level_op *
+    get() const
+    {
+      return h.get();
+    }
+
+  private:
+    std::shared_ptr<mgamd_level_op> h;
+  };
+
+  class PreconditionChebyshev
+  {
+  public:
+    struct AdditionalData
+    {
+      double   smoothing_range     = 20.;
+      unsigned degree              = 5;
+      unsigned eig_cg_n_iterations = 20;
+    };
+    void
+    initialize(const Operator &matrix, const AdditionalData &data)
+    {
+      mgamd_cheb *c = nullptr;
+      check(mgamd_cheb_create(matrix.get(), data.degree, data.smoothing_range, data.eig_cg_n_iterations, &c));
+      h.reset(c, mgamd_cheb_destroy);
+    }
+    void
+    vmult(Vector &dst, const Vector &src) const
+    {
+      check(mgamd_cheb_vmult(h.get(), dst.get(), src.get()));
+    }
+    void
+    step(Vector &dst, const Vector &src) const
+    {
+      check(mgamd_cheb_step(h.get(), dst.get(), src.get()));
+    }
+    mgamd_cheb *
+    get() const
+    {
+      return h.get();
+    }
+
+  private:
+    std::shared_ptr<mgamd_cheb> h;
+  };
+
+  class MGTwoLevelTransfer
+  {
+  public:
+    // reinit(dof_fine, dof_coarse, constraint_fine, constraint_coarse): the level operators carry all four
+    void
+    reinit(const Operator &fine, const Operator &coarse)
+    {
+      mgamd_transfer2 *t = nullptr;
+      check(mgamd_transfer2_create(fine.get(), coarse.get(), &t));
+      h.reset(t, mgamd_transfer2_destroy);
+    }
+    void
+    prolongate_and_add(Vector &dst, const Vector &src) const
+    {
+      check(mgamd_transfer2_prolongate_and_add(h.get(), dst.get(), src.get()));
+    }
+    void
+    restrict_and_add(Vector &dst, const Vector &src) const
+    {
+      check(mgamd_transfer2_restrict_and_add(h.get(), dst.get(), src.get()));
+    }
+    mgamd_transfer2 *
+    get() const
+    {
+      return h.get();
+    }
+
+  private:
+    std::shared_ptr<mgamd_transfer2> h;
+  };
+
+  // Multigrid<VectorType> + PreconditionMG<dim,VectorType,MGTransferGlobalCoarsening> in one object
+  class PreconditionMG
+  {
+  public:
+    using StageSlot = std::function<void(bool /*start*/, unsigned /*level*/)>;
+    PreconditionMG(const Context &ctx, const std::vector<Operator> &mg_matrices, const std::vector<MGTwoLevelTransfer> &transfers,
+                   const std::vector<PreconditionChebyshev> &smoothers, const std::string &coarse_grid_solver_type)
+    {
+      const unsigned                 n = mg_matrices.size();
+      std::vector<mgamd_level_op *>  L(n);
+      std::vector<mgamd_transfer2 *> T(n, nullptr);
+      std::vector<mgamd_cheb *>      S(n);
+      for (unsigned l = 0; l < n; ++l)
+        {
+          L[l] = mg_matrices[l].get();
+          S[l] = smoothers[l].get();
+          if (l > 0)
+            T[l] = transfers[l].get();
+        }
+      mgamd_mg *m = nullptr;
+      check(mgamd_mg_create(ctx.get(), n, L.data(), T.data(), S.data(), coarse_grid_solver_type.c_str(), &m));
+      h.reset(m, mgamd_mg_destroy);
+      slots.resize(9);
+    }
+    void
+    vmult(Vector &dst, const Vector &src) const
+    {
+      check(mgamd_mg_vcycle(h.get(), dst.get(), src.get()));
+    }
+    // Multigrid::connect_* / PreconditionMG::connect_transfer_to_* (ref:multigrid_throughput.cc:1183-1192,1233-1234)
+    void
+    connect_pre_smoother_step(StageSlot s)
+    {
+      connect(0, std::move(s));
+    }
+    void
+    connect_residual_step(StageSlot s)
+    {
+      connect(1, std::move(s));
+    }
+    void
+    connect_restriction(StageSlot s)
+    {
+      connect(2, std::move(s));
+    }
+    void
+    connect_coarse_solve(StageSlot s)
+    {
+      connect(3, std::move(s));
+    }
+    void
+    connect_prolongation(StageSlot s)
+    {
+      connect(4, std::move(s));
+    }
+    void
+    connect_edge_prolongation(StageSlot s)
+    {
+      connect(5, std::move(s));
+    }
+    void
+    connect_post_smoother_step(StageSlot s)
+    {
+      connect(6, std::move(s));
+    }
+    void
+    connect_transfer_to_mg(std::function<void(bool)> s)
+    {
+      connect(7, [s](bool f, unsigned) { s(f); });
+    }
+    void
+    connect_transfer_to_global(std::function<void(bool)> s)
+    {
+      connect(8, [s](bool f, unsigned) { s(f); });
+    }
+    void
+    disconnect_all()
+    {
+      for (auto &s : slots)
+        s = nullptr;
+      check(mgamd_mg_set_stage_callback(h.get(), nullptr, nullptr));
+    }
+    mgamd_mg *
+    get() const
+    {
+      return h.get();
+    }
+
+  private:
+    void
+    connect(int stage, StageSlot s)
+    {
+      slots[stage] = std::move(s);
+      check(mgamd_mg_set_stage_callback(h.get(), &PreconditionMG::trampoline, this));
+    }
+    static void
+    trampoline(int stage, int start, unsigned level, void *user)
+    {
+      auto *self = static_cast<PreconditionMG *>(user);
+      if (stage >= 0 && stage < (int)self->slots.size() && self->slots[stage])
+        self->slots[stage](start != 0, level);
+    }
+    std::shared_ptr<mgamd_mg> h;
+    std::vector<StageSlot>    slots;
+  };
+
+  class ReductionControl
+  {
+  public:
+    ReductionControl(unsigned maxiter = 10000, double abstol = 1e-20, double reltol = 1e-4)
+      : maxiter(maxiter)
+      , abstol(abstol)
+      , reltol(reltol)
+    {}
+    unsigned
+    last_step() const
+    {
+      return steps;
+    }
+    double
+    last_value() const
+    {
+      return value;
+    }
+    unsigned maxiter;
+    double   abstol, reltol;
+    unsigned steps = 0;
+    double   value = 0;
+  };
+
+  class SolverCG
+  {
+  public:
+    explicit SolverCG(ReductionControl &control)
+      : control(control)
+    {}
+    // solve(A, x, b, preconditioner) starting from x = 0; non-convergence is reported through last_step()
+    // == maxiter like the reference, which swallows SolverControl::NoConvergence (ref:multigrid_throughput.cc:1146,1250)
+    void
+    solve(const Operator &A, Vector &x, const Vector &b, const PreconditionMG &preconditioner)
+    {
+      check(mgamd_solve_cg(A.get(), preconditioner.get(), x.get(), b.get(), control.reltol, control.abstol, control.maxiter,
+                           &control.steps, &control.value));
+    }
+
+  private:
+    ReductionControl &control;
+  };
+} // namespace mgamd

@@ -1,0 +1,486 @@
+// multigrid_throughput -- JSON-in / table-out harness of the MI355X-native path, mirroring the reference's
+// driver (ref:multigrid_throughput.cc:1970-2470): same 17 JSON keys (RunParameters::parse, :1989-2014), same
+// run protocol (1 warm-up solve, then n_repetitions = 5 timed solves, best time wins, :1140-1147,1238-1268),
+// same table columns in the same order (:2328-2335, 1488, 1278-1283, 1381-1401).
+//
+//   ./multigrid_throughput input_0000.json [input_0001.json ...]
+//
+// Implemented `Type`s: HMG-global, PMG (global coarsening).  HMG-local/HPMG-local/AMG/AMGPETSc/HPMG raise
+// "not implemented" exactly like the reference's AssertThrow(false, ExcNotImplemented()) for unknown strings.
+#include "../csrc/mgamd.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <map>
+#include <sstream>
+
+using namespace mgamd;
+
+// ---- ScopedTimer (ref:include/scoped_timer.h:1-20) ---------------------------------------------------------
+class ScopedTimer
+{
+public:
+  explicit ScopedTimer(double &result)
+    : result(result)
+    , start(std::chrono::system_clock::now())
+  {}
+  ~ScopedTimer()
+  {
+    result += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::system_clock::now() - start).count() / 1e9;
+  }
+
+private:
+  double                                            &result;
+  std::chrono::time_point<std::chrono::system_clock> start;
+};
+
+// ---- minimal JSON object reader (flat object; values: string | number | true | false) ----------------------
+static std::map<std::string, std::string>
+parse_json_object(const std::string &file_name)
+{
+  std::ifstream f(file_name);
+  if (!f)
+    throw std::runtime_error("cannot open " + file_name);
+  std::stringstream ss;
+  ss << f.rdbuf();
+  const std::string                  s = ss.str();
+  std::map<std::string, std::string> out;
+  size_t                             i = 0;
+  auto skip = [&]() {
+    while (i < s.size() && (isspace((unsigned char)s[i]) || s[i] == ',' || s[i] == ':'))
+      ++i;
+  };
+  auto read_string = [&]() {
+    std::string r;
+    ++i;
+    while (i < s.size() && s[i] != '"')
+      {
+        if (s[i] == '\\' && i + 1 < s.size())
+          ++i;
+        r += s[i++];
+      }
+    ++i;
+    return r;
+  };
+  skip();
+  if (i >= s.size() || s[i] != '{')
+    throw std::runtime_error(file_name + ": not a JSON object");
+  ++i;
+  while (true)
+    {
+      skip();
+      if (i >= s.size() || s[i] == '}')
+        break;
+      if (s[i] != '"')
+        throw std::runtime_error(file_name + ": expected a key");
+      const std::string key = read_string();
+      skip();
+      std::string value;
+      if (s[i] == '"')
+        value = read_string();
+      else
+        while (i < s.size() && s[i] != ',' && s[i] != '}' && !isspace((unsigned char)s[i]))
+          value += s[i++];
+      out[key] = value;
+    }
+  return out;
+}
+
+// ---- parameters (ref:multigrid_throughput.cc:297-334, 1970-2015) -------------------------------------------
+struct MultigridParameters
+{
+  struct
+  {
+    std::string type    = "amg";
+    unsigned    maxiter = 10000;
+    double      abstol  = 1e-20;
+    double      reltol  = 1e-4;
+    unsigned    n_cycles = 1;
+  } coarse_solver;
+  struct
+  {
+    double   smoothing_range     = 20;
+    unsigned degree              = 5;
+    unsigned eig_cg_n_iterations = 20;
+  } smoother;
+  struct
+  {
+    unsigned maxiter = 10000;
+    double   abstol  = 1e-20;
+    double   reltol  = 1e-4;
+  } cg_normal;
+  unsigned n_repetitions = 5;
+};
+
+struct RunParameters
+{
+  std::string  type            = "PMG";
+  std::string  geometry_type   = "quadrant_flexible";
+  unsigned     n_ref_global    = 6;
+  unsigned     n_ref_local     = 0;
+  unsigned     fe_degree_fine  = 4;
+  bool         paraview        = false;
+  bool         verbose         = true;
+  unsigned     p               = 0;
+  std::string  policy_name     = "";
+  std::string  mg_number_type  = "float";
+  std::string  simulation_type = "Constant";
+  int          min_level       = -1;
+  int          min_n_cells     = -1;
+  MultigridParameters mg_data;
+
+  void
+  parse(const std::string &file_name)
+  {
+    const auto kv  = parse_json_object(file_name);
+    auto       get = [&](const char *k, auto &dst) {
+      auto it = kv.find(k);
+      if (it == kv.end())
+        return;
+      using D = std::decay_t<decltype(dst)>;
+      if constexpr (std::is_same<D, std::string>::value)
+        dst = it->second;
+      else if constexpr (std::is_same<D, bool>::value)
+        dst = it->second == "true" || it->second == "1";
+      else if constexpr (std::is_floating_point<D>::value)
+        dst = std::stod(it->second);
+      else
+        dst = (D)std::stol(it->second);
+    };
+    get("Type", type);
+    get("GeometryType", geometry_type);
+    get("NRefGlobal", n_ref_global);
+    get("NRefLocal", n_ref_local);
+    get("Degree", fe_degree_fine);
+    get("Paraview", paraview);
+    get("Verbosity", verbose);
+    get("Partitioner", p);
+    get("PartitionerName", policy_name);
+    get("MinLevel", min_level);
+    get("MinNCells", min_n_cells);
+    get("CoarseGridSolverType", mg_data.coarse_solver.type);
+    get("SmootherDegree", mg_data.smoother.degree);
+    get("CoarseSolverNCycles", mg_data.coarse_solver.n_cycles);
+    get("RelativeTolerance", mg_data.cg_normal.reltol);
+    get("MGNumberType", mg_number_type);
+    get("SimulationType", simulation_type); // unknown keys are ignored (skip_undefined = true)
+  }
+};
+
+// ---- ConvergenceTable stand-in -------------------------------------------------------------------------------
+class ConvergenceTable
+{
+public:
+  template <typename V>
+  void
+  add_value(const std::string &key, const V &value, bool scientific = false)
+  {
+    std::ostringstream os;
+    if (scientific)
+      os << std::scientific << std::setprecision(4) << (double)value;
+    else
+      os << value;
+    if (std::find(order.begin(), order.end(), key) == order.end())
+      order.push_back(key);
+    columns[key].push_back(os.str());
+  }
+  void
+  write_text(std::ostream &out) const
+  {
+    std::vector<size_t> w;
+    size_t              rows = 0;
+    for (const auto &k : order)
+      {
+        size_t m = k.size();
+        for (const auto &v : columns.at(k))
+          m = std::max(m, v.size());
+        w.push_back(m);
+        rows = std::max(rows, columns.at(k).size());
+      }
+    for (size_t c = 0; c < order.size(); ++c)
+      out << std::left << std::setw(w[c] + 1) << order[c];
+    out << "\n";
+    for (size_t r = 0; r < rows; ++r)
+      {
+        for (size_t c = 0; c < order.size(); ++c)
+          {
+            const auto &col = columns.at(order[c]);
+            out << std::left << std::setw(w[c] + 1) << (r < col.size() ? col[r] : "");
+          }
+        out << "\n";
+      }
+    out << std::flush;
+  }
+
+private:
+  std::vector<std::string>                        order;
+  std::map<std::string, std::vector<std::string>> columns;
+};
+
+static std::string
+resolve_policy_name(const RunParameters &params)
+{
+  // ref:multigrid_throughput.cc:2074-2105
+  if (!params.policy_name.empty())
+    return params.policy_name;
+  static const char *names[] = {"DefaultPolicy", "MinimalGranularityPolicy-40", "CellWeightPolicy-1.0", "CellWeightPolicy-1.5",
+                                "CellWeightPolicy-2.0", "CellWeightPolicy-2.5", "FirstChildPolicy", "BalancedGranularityPartitionPolicy"};
+  if (params.p > 7)
+    throw std::runtime_error("Partitioner: not implemented");
+  return names[params.p];
+}
+
+static void
+run(const Context &ctx, const RunParameters &params, ConvergenceTable &table)
+{
+  const std::string policy = resolve_policy_name(params);
+  {
+    // the partitioning policy only matters across ranks; validate the name like ref:multigrid_throughput.cc:2127-2174
+    auto pre = [&](const char *x) { return policy.rfind(x, 0) == 0; };
+    if (!(policy == "DefaultPolicy" || policy == "BalancedGranularityPartitionPolicy" || pre("MinimalGranularityPolicy") ||
+          pre("CellWeightPolicy") || pre("FirstChildPolicy")))
+      throw std::runtime_error("PartitionerName '" + policy + "': not implemented");
+  }
+  if (params.simulation_type != "Constant")
+    throw std::runtime_error("SimulationType '" + params.simulation_type + "': not implemented (f = 1, g = 0 only)");
+  int level_number_type;
+  if (params.mg_number_type == "double")
+    level_number_type = MGAMD_F64;
+  else if (params.mg_number_type == "float")
+    level_number_type = MGAMD_F32;
+  else
+    throw std::runtime_error("MGNumberType '" + params.mg_number_type + "': not implemented");
+
+  auto tria = std::make_shared<const Triangulation>(params.geometry_type, params.n_ref_global, params.n_ref_local);
+
+  // ---- level hierarchy (ref:multigrid_throughput.cc:2219-2260, 1506-1596)
+  std::vector<std::shared_ptr<const Triangulation>> triangulations;
+  std::vector<unsigned>                             degrees;
+  if (params.type == "HMG-global")
+    {
+      triangulations = create_geometric_coarsening_sequence(tria);
+      if (triangulations.size() > 1)
+        {
+          auto ptr = std::find_if(triangulations.begin(), triangulations.end() - 1, [&](const auto &t) {
+            if (params.min_level != -1)
+              return params.min_level <= (int)t->n_global_levels();
+            if (params.min_n_cells != -1)
+              return (int)t->n_global_active_cells() >= params.min_n_cells;
+            return true;
+          });
+          triangulations.erase(triangulations.begin(), ptr);
+        }
+      degrees.assign(triangulations.size(), params.fe_degree_fine);
+    }
+  else if (params.type == "PMG")
+    {
+      degrees = create_polynomial_coarsening_sequence(params.fe_degree_fine);
+      triangulations.assign(degrees.size(), tria);
+    }
+  else
+    throw std::runtime_error("Type '" + params.type + "': not implemented");
+
+  const unsigned                  n_levels = degrees.size();
+  std::vector<DoFHandler>         dof_handlers;
+  std::vector<Operator>           operators(n_levels);
+  std::vector<MGTwoLevelTransfer> transfers(n_levels);
+  std::vector<PreconditionChebyshev> smoothers(n_levels);
+  for (unsigned l = 0; l < n_levels; ++l)
+    dof_handlers.emplace_back(triangulations[l], degrees[l]);
+  for (unsigned l = 0; l < n_levels; ++l)
+    operators[l].reinit(ctx, dof_handlers[l], level_number_type);
+  for (unsigned l = 1; l < n_levels; ++l)
+    transfers[l].reinit(operators[l], operators[l - 1]);
+  PreconditionChebyshev::AdditionalData sd;
+  sd.smoothing_range     = params.mg_data.smoother.smoothing_range;
+  sd.degree              = params.mg_data.smoother.degree;
+  sd.eig_cg_n_iterations = params.mg_data.smoother.eig_cg_n_iterations;
+  for (unsigned l = 0; l < n_levels; ++l)
+    smoothers[l].initialize(operators[l], sd);
+
+  // coarse solver: the Trilinos/PETSc AMG options degenerate to a direct solve on a one-cell coarse level; on
+  // larger coarse levels (PMG, MinLevel) fall back to the reference's Trilinos-free "cg_with_chebyshev"
+  std::string coarse = params.mg_data.coarse_solver.type;
+  if ((coarse == "amg" || coarse == "cg_with_amg" || coarse == "amg_petsc") && dof_handlers[0].n_dofs() > 4096)
+    {
+      std::cout << "note: CoarseGridSolverType '" << coarse << "' needs Trilinos/PETSc; using cg_with_chebyshev on the "
+                << dof_handlers[0].n_dofs() << "-DoF coarse level" << std::endl;
+      coarse = "cg_with_chebyshev";
+    }
+  PreconditionMG preconditioner(ctx, operators, transfers, smoothers, coarse);
+
+  // fine (outer, double) operator, right-hand side (ref:multigrid_throughput.cc:2262-2324)
+  Operator op;
+  if (level_number_type == MGAMD_F64)
+    op = operators.back();
+  else
+    op.reinit(ctx, dof_handlers.back(), MGAMD_F64);
+  Vector solution, rhs;
+  op.initialize_dof_vector(solution);
+  op.initialize_dof_vector(rhs);
+  op.rhs(rhs);
+
+  table.add_value("dim", 3);
+  table.add_value("n_cells", tria->n_global_active_cells());
+  table.add_value("n_cells_hn", tria->n_cells_with_hanging_nodes());
+  table.add_value("n_cells_n", tria->n_global_active_cells() - tria->n_cells_with_hanging_nodes());
+  table.add_value("degree", params.fe_degree_fine);
+  table.add_value("n_ref_global", params.n_ref_global);
+  table.add_value("n_ref_local", params.n_ref_local);
+  table.add_value("n_dofs", dof_handlers.back().n_dofs());
+  table.add_value("sub_comm_size", 1);
+
+  if (params.verbose)
+    {
+      ConvergenceTable t;
+      for (unsigned l = 0; l < n_levels; ++l)
+        {
+          t.add_value("cells", triangulations[l]->n_global_active_cells());
+          t.add_value("dofs", dof_handlers[l].n_dofs());
+        }
+      t.write_text(std::cout);
+    }
+
+  // ---- solve protocol (ref:multigrid_throughput.cc:1137-1268)
+  ReductionControl solver_control(params.mg_data.cg_normal.maxiter, params.mg_data.cg_normal.abstol, params.mg_data.cg_normal.reltol);
+  ctx.synchronize();
+  solution = 0.0;
+  SolverCG(solver_control).solve(op, solution, rhs, preconditioner); // warm-up
+
+  const unsigned n_repetitions = params.mg_data.n_repetitions;
+  unsigned       counter       = 0;
+  using TP                     = std::chrono::time_point<std::chrono::system_clock>;
+  std::vector<std::vector<std::vector<std::pair<double, TP>>>> all_mg_timers(
+    n_repetitions, std::vector<std::vector<std::pair<double, TP>>>(n_levels, std::vector<std::pair<double, TP>>(7)));
+  std::vector<std::vector<std::pair<double, TP>>> all_mg_precon_timers(n_repetitions, std::vector<std::pair<double, TP>>(2));
+  auto mg_timer = [&](unsigned i) {
+    return [i, &all_mg_timers, &counter](bool flag, unsigned level) {
+      auto &t = all_mg_timers[counter][level][i];
+      if (flag)
+        t.second = std::chrono::system_clock::now();
+      else
+        t.first += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::system_clock::now() - t.second).count() / 1e9;
+    };
+  };
+  auto precon_timer = [&](unsigned i) {
+    return [i, &all_mg_precon_timers, &counter](bool flag) {
+      auto &t = all_mg_precon_timers[counter][i];
+      if (flag)
+        t.second = std::chrono::system_clock::now();
+      else
+        t.first += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::system_clock::now() - t.second).count() / 1e9;
+    };
+  };
+  preconditioner.connect_pre_smoother_step(mg_timer(0));
+  preconditioner.connect_residual_step(mg_timer(1));
+  preconditioner.connect_restriction(mg_timer(2));
+  preconditioner.connect_coarse_solve(mg_timer(3));
+  preconditioner.connect_prolongation(mg_timer(4));
+  preconditioner.connect_edge_prolongation(mg_timer(5));
+  preconditioner.connect_post_smoother_step(mg_timer(6));
+  preconditioner.connect_transfer_to_mg(precon_timer(0));
+  preconditioner.connect_transfer_to_global(precon_timer(1));
+
+  std::vector<double> times(n_repetitions);
+  for (; counter < n_repetitions; ++counter)
+    {
+      ctx.synchronize(); // MPI_Barrier
+      double time = 0.0;
+      {
+        solution = 0.0;
+        ScopedTimer timer(time);
+        SolverCG(solver_control).solve(op, solution, rhs, preconditioner);
+      }
+      times[counter] = time;
+    }
+  preconditioner.disconnect_all();
+  const unsigned min_index = std::min_element(times.begin(), times.end()) - times.begin();
+  const double   time      = times[min_index];
+  const auto    &mg_timers = all_mg_timers[min_index];
+  double         time_cg   = time;
+  for (const auto &lv : mg_timers)
+    for (const auto &st : lv)
+      time_cg -= st.first;
+  for (const auto &st : all_mg_precon_timers[min_index])
+    time_cg -= st.first;
+  const unsigned its = std::max(1u, solver_control.last_step());
+  table.add_value("n_levels", n_levels);
+  table.add_value("n_iterations", solver_control.last_step());
+  table.add_value("time", time);
+  table.add_value("time_cg", time_cg / its);
+  table.add_value("throughput", (double)rhs.size() * solver_control.last_step() / time, true);
+  static const char *stage_cols[7] = {"time_pre", "time_residuum", "time_res", "time_cs", "time_pro", "time_edge_pro", "time_post"};
+  double             t_v           = 0.0;
+  for (unsigned j = 0; j < 7; ++j)
+    {
+      double s = 0;
+      for (unsigned l = 0; l < n_levels; ++l)
+        s += mg_timers[l][j].first / its;
+      t_v += s;
+      table.add_value(stage_cols[j], s, true);
+    }
+  table.add_value("time_to_mg", all_mg_precon_timers[min_index][0].first / its, true);
+  table.add_value("time_to_global", all_mg_precon_timers[min_index][1].first / its, true);
+  t_v += (all_mg_precon_timers[min_index][0].first + all_mg_precon_timers[min_index][1].first) / its;
+  // this project's unit: DoF/s per V-cycle = n_dofs / (sum of the nine stage columns)
+  table.add_value("dofs_per_s_per_vcycle", (double)rhs.size() / t_v, true);
+
+  if (params.verbose)
+    {
+      std::cout << "per-level stage times per CG iteration [s] (pre, residuum, res, cs, pro, edge_pro, post):" << std::endl;
+      for (unsigned l = 0; l < n_levels; ++l)
+        {
+          std::cout << "  level " << l << ":";
+          for (unsigned j = 0; j < 7; ++j)
+            std::cout << " " << std::scientific << std::setprecision(3) << mg_timers[l][j].first / its;
+          std::cout << std::endl;
+        }
+    }
+}
+
+int
+main(int argc, char **argv)
+{
+  try
+    {
+      if (argc == 1)
+        {
+          printf("ERROR: No .json parameter files has been provided!\n");
+          return 1;
+        }
+      Context          ctx(0);
+      ConvergenceTable table;
+      for (int i = 1; i < argc; i++)
+        {
+          std::cout << std::string(argv[i]) << std::endl;
+          RunParameters params;
+          params.parse(std::string(argv[i]));
+          run(ctx, params, table);
+          table.write_text(std::cout);
+        }
+      table.write_text(std::cout);
+    }
+  catch (std::exception &exc)
+    {
+      std::cerr << std::endl
+                << std::endl
+                << "----------------------------------------------------" << std::endl;
+      std::cerr << "Exception on processing: " << std::endl << exc.what() << std::endl << "Aborting!" << std::endl
+                << "----------------------------------------------------" << std::endl;
+      return 1;
+    }
+  catch (...)
+    {
+      std::cerr << std::endl
+                << std::endl
+                << "----------------------------------------------------" << std::endl;
+      std::cerr << "Unknown exception!" << std::endl << "Aborting!" << std::endl
+                << "----------------------------------------------------" << std::endl;
+      return 1;
+    }
+  return 0;
+}
