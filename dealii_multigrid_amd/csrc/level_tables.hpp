@@ -34,21 +34,31 @@ namespace mgamd
     return B;
   }
 
-  // position of lattice node (x,y,z) in the shell enumeration (lexicographic z,y,x skipping the interior)
+  // position of lattice node (x,y,z) in the shell enumeration.  The shell is listed FACE BY FACE -- z=0, z=N-1,
+  // then y=0, y=N-1 (without the z-face rows), then x=0, x=N-1 (without the y- and z-face rows) -- each face as a
+  // contiguous 2D block in (outer, inner) lexicographic order.  Tail DoFs are numbered in first-touch order of
+  // this enumeration, so a face shared by two bricks is ONE contiguous run of the tail segment for both of
+  // them: shell gathers and shell atomics of a wave hit consecutive addresses (measured: 2.7x over-fetch with
+  // the plain lattice-order enumeration).
   inline int
   shell_slot_of(int N, int x, int y, int z)
   {
-    const int ring = N * N - (N - 2) * (N - 2);
+    const int M = N - 2;
     if (z == 0)
       return y * N + x;
     if (z == N - 1)
-      return N * N + (N - 2) * ring + y * N + x;
-    int s = N * N + (z - 1) * ring;
+      return N * N + y * N + x;
+    int s = 2 * N * N;
     if (y == 0)
-      return s + x;
+      return s + (z - 1) * N + x;
+    s += M * N;
     if (y == N - 1)
-      return s + N + (N - 2) * 2 + x;
-    return s + N + (y - 1) * 2 + (x == 0 ? 0 : 1);
+      return s + (z - 1) * N + x;
+    s += M * N;
+    if (x == 0)
+      return s + (z - 1) * M + (y - 1);
+    s += M * M;
+    return s + (z - 1) * M + (y - 1);
   }
 
   struct SlotGroup
