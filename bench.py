@@ -104,8 +104,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--nref", type=int, default=7, help="NRefGlobal of the primary workload (octant p=4)")
-    ap.add_argument("--nref-p1", type=int, default=8, help="NRefGlobal of the secondary octant p=1 workload")
+    ap.add_argument("--nref", type=int, default=8, help="NRefGlobal of the primary workload (octant p=4)")
+    ap.add_argument("--nref-p1", type=int, default=9, help="NRefGlobal of the secondary octant p=1 workload")
     ap.add_argument("--cpu-nref", type=int, default=6, help="NRefGlobal of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
