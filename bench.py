@@ -173,7 +173,7 @@ def main():
         B = max(prim["groups"], key=lambda g: g[1] * (4 * g[0] + 1) ** 3)[0]
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                            "traffic": pmc_traffic(args.nref, B),
-                           "kernel": f"lattice_apply_kernel<double,4,{B},MODE_CHEB> (Chebyshev pass with x_old: 5 words/DoF)",
+                           "kernel": f"lattice_apply_kernel<double,4,{B},MODE_CHEB> (all Chebyshev passes: 5 words/DoF with x_old, 4 without)",
                            "launches": n, "avg_launch_us": ms / n * 1e3, "algorithmic_bytes_per_launch": by / n}
     if rank == 0 and not args.no_secondary:
         sec = run_workload(m, ctx, "quadrant", args.nref_p1, 1, args.steps, args.warmup, lambda: None, sync, profile=False)

@@ -367,7 +367,7 @@ namespace mgamd
             continue;
           a.g      = g->view();
           a.stamps = (stamps.p && g->B == prof_B && MODE == stamp_mode && !diag) ? stamps.p : nullptr;
-          const bool prof = ctx->profile && !diag && MODE == MODE_CHEB && g->B == prof_B && epi.xold != nullptr;
+          const bool prof = ctx->profile && !diag && MODE == MODE_CHEB && g->B == prof_B;
           if (prof)
             {
               if (ctx->prof_used == ctx->prof_events.size())

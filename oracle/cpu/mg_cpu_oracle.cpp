@@ -978,4 +978,9 @@ mgo_num_threads(void)
 {
   return omp_get_max_threads();
 }
+void
+mgo_set_num_threads(int n)
+{
+  omp_set_num_threads(n);
+}
 }

@@ -36,6 +36,8 @@ def _load():
     lib.mgo_mg_create.restype = C.c_void_p
     lib.mgo_mg_max_eigenvalue.restype = C.c_double
     lib.mgo_mg_time_vcycles.restype = C.c_double
+    # libgomp may already be initialised (torch/numpy) with the machine's core count: set the team size explicitly
+    lib.mgo_set_num_threads(int(os.environ["OMP_NUM_THREADS"]))
     return lib
 
 

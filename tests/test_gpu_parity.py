@@ -204,3 +204,36 @@ def test_size_independent_properties_at_scale(mgamd, ctx):
         assert rel_err(Aw.to_host(), 2.0 * Au.to_host() - 3.0 * Av.to_host()) < 1e-13  # linearity
         first_c = d.info.n_interior + d.info.n_tail
         assert np.array_equal(Au.to_host()[first_c:], u[first_c:])  # identity rows (ref:include/operator.h:170-172)
+
+
+@pytest.mark.parametrize("geo,L,p,mg_type", [("quadrant", 3, 1, "HMG-global"), ("quadrant", 3, 4, "HMG-global"), ("annulus", 5, 2, "HMG-global"),
+                                             ("quadrant", 3, 4, "PMG")])
+def test_float_levels_mixed_precision(mgamd, oracle, ctx, geo, L, p, mg_type):
+    """MGNumberType float (the reference's default, ref:multigrid_throughput.cc:2430-2433, ref:scripts/default.json:16):
+    FP32 V-cycle under the FP64 outer CG.  Operator/transfer agree with the FP64 oracle to FP32 rounding, the
+    preconditioned solve needs the same number of iterations and reaches the same solution to the CG tolerance."""
+    h = mgamd.Hierarchy(ctx, geo, L, p, mg_type, coarse_solver="amg", number_type=mgamd.F32)
+    levels, P = oracle.build_hierarchy(geo, L, p, mg_type, numbering_keys=[d.keys() for d in h.dofs])
+    rng = np.random.default_rng(21)
+    for l, op in enumerate(h.operators):
+        x = rng.standard_normal(levels[l].n)
+        src, dst = op.initialize_dof_vector().from_host(x), op.initialize_dof_vector()
+        op.vmult(dst, src)
+        assert rel_err(dst.to_host(), levels[l].A @ x) < 2e-6
+        if l > 0:
+            xc = rng.standard_normal(levels[l - 1].n)
+            vc, vf = h.operators[l - 1].initialize_dof_vector().from_host(xc), h.operators[l].initialize_dof_vector()
+            h.transfers[l].prolongate_and_add(vf, vc)
+            assert rel_err(vf.to_host(), P[l] @ xc) < 2e-6
+    mg = oracle.Multigrid(levels, P, 3)
+    r = rng.standard_normal(levels[-1].n)
+    vr, vz = mgamd.Vector(ctx, levels[-1].n).from_host(r), mgamd.Vector(ctx, levels[-1].n)
+    h.mg.vmult(vz, vr)  # double in, float V-cycle, double out
+    assert rel_err(vz.to_host(), mg.vcycle(r)) < 5e-5
+    Lf = levels[-1]
+    xref, itref, hist = oracle.pcg(Lf.A, Lf.rhs_constant, mg.vcycle, 1e-4)
+    b, x = h.fine_operator.initialize_dof_vector(), h.fine_operator.initialize_dof_vector()
+    h.fine_operator.rhs(b)
+    it, res = mgamd.solve_cg(h.fine_operator, h.mg, x, b, 1e-4)
+    assert abs(it - itref) <= 1
+    assert rel_err(x.to_host(), xref) < 1e-3
