@@ -941,6 +941,324 @@ namespace mgamd
   }
 
   // ------------------------------------------------------------------------------------------
+  // Brick-level h-transfer: one fine brick (lattice NF = P*B+1) <-> the (B/2)^3 coarse cells under it
+  // (lattice NC = P*B/2+1).  Interior fine DoFs are contiguous (coalesced read-modify-write); the shell
+  // uses the brick's ownership list.  Restriction adds to the coarse vector with plain read-modify-write
+  // for coarse lattice nodes strictly inside the patch (no other patch touches them) and atomics only on
+  // its surface.
+  // ------------------------------------------------------------------------------------------
+  template <int P, int B>
+  struct BrickTransferGeo
+  {
+    static constexpr int NF    = P * B + 1;
+    static constexpr int BC    = B / 2;
+    static constexpr int NC    = P * BC + 1;
+    static constexpr int NF3   = NF * NF * NF;
+    static constexpr int NC3   = NC * NC * NC;
+    static constexpr int S1    = NF * NC * NC; // after the z sweep
+    static constexpr int S2    = NF * NF * NC; // after the y sweep
+    static constexpr int BLOCK = 256;
+    static constexpr int LDS   = NC3 + S1 + S2 + NF3;
+  };
+
+  template <typename T, int P>
+  struct BrickTransferArgs
+  {
+    const uint32_t *slot;          // [n_bricks] fine slot index
+    const uint32_t *interior_base; // fine group's table
+    const uint16_t *shell_pos;     // fine group's table
+    const uint32_t *coarse_idx;    // [n_bricks][NC3]
+    const uint32_t *own_shell;     // [n_bricks][N_SHELL]
+    uint32_t        n_bricks;
+    double          E[(2 * P + 1) * (P + 1)];
+    const T        *src;
+    T              *dst;
+  };
+
+  // fine line (P*BC*2+1) from coarse line (P*BC+1), cell by cell
+  template <typename T, int P, int BC>
+  __device__ __forceinline__ void
+  line_embed(const double *__restrict__ E, const T (&in)[P * BC + 1], T (&out)[2 * P * BC + 1])
+  {
+#pragma unroll
+    for (int c = 0; c < BC; ++c)
+#pragma unroll
+      for (int a = (c == 0 ? 0 : 1); a <= 2 * P; ++a)
+        {
+          T s = T(0);
+#pragma unroll
+          for (int b = 0; b <= P; ++b)
+            s += T(E[a * (P + 1) + b]) * in[c * P + b];
+          out[c * 2 * P + a] = s;
+        }
+  }
+  // transpose: coarse line += E^T fine line; fine nodes shared by two coarse cells are counted once
+  template <typename T, int P, int BC>
+  __device__ __forceinline__ void
+  line_embed_T(const double *__restrict__ E, const T (&in)[2 * P * BC + 1], T (&out)[P * BC + 1])
+  {
+#pragma unroll
+    for (int i = 0; i < P * BC + 1; ++i)
+      out[i] = T(0);
+#pragma unroll
+    for (int c = 0; c < BC; ++c)
+#pragma unroll
+      for (int a = (c == 0 ? 0 : 1); a <= 2 * P; ++a)
+#pragma unroll
+        for (int b = 0; b <= P; ++b)
+          out[c * P + b] += T(E[a * (P + 1) + b]) * in[c * 2 * P + a];
+  }
+
+  template <typename T, int P, int B>
+  __global__ void
+  __launch_bounds__(256) brick_prolongate_kernel(const BrickTransferArgs<T, P> args)
+  {
+    using G  = BrickTransferGeo<P, B>;
+    using LG = Geo<P, B>;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    T *bufC = reinterpret_cast<T *>(smem_raw); // NC3
+    T *buf1 = bufC + G::NC3;                   // (Z, y, x): NF x NC x NC
+    T *buf2 = buf1 + G::S1;                    // (Z, Y, x): NF x NF x NC
+    T *bufF = buf2 + G::S2;                    // fine lattice NF3
+    constexpr int NC = G::NC, NF = G::NF, BLOCK = G::BLOCK;
+    const int      tid   = threadIdx.x;
+    const uint32_t brick = blockIdx.x;
+    const uint32_t slot  = args.slot[brick];
+
+    {
+      constexpr int ITC = (G::NC3 + BLOCK - 1) / BLOCK;
+      uint32_t      gi[ITC];
+      T             val[ITC];
+#pragma unroll
+      for (int it = 0; it < ITC; ++it)
+        {
+          const int idx = tid + it * BLOCK;
+          gi[it]        = idx < G::NC3 ? args.coarse_idx[(size_t)brick * G::NC3 + idx] : DEV_INVALID;
+        }
+#pragma unroll
+      for (int it = 0; it < ITC; ++it)
+        val[it] = args.src[gi[it] != DEV_INVALID ? gi[it] : 0];
+#pragma unroll
+      for (int it = 0; it < ITC; ++it)
+        if (tid + it * BLOCK < G::NC3)
+          bufC[tid + it * BLOCK] = gi[it] != DEV_INVALID ? val[it] : T(0);
+    }
+    __syncthreads();
+    T in[NC], out[NF];
+    // z: lines (x,y) of the coarse lattice
+    for (int l = tid; l < NC * NC; l += BLOCK)
+      {
+        const int x = l % NC, y = l / NC;
+#pragma unroll
+        for (int i = 0; i < NC; ++i)
+          in[i] = bufC[(i * NC + y) * NC + x];
+        line_embed<T, P, G::BC>(args.E, in, out);
+#pragma unroll
+        for (int i = 0; i < NF; ++i)
+          buf1[(i * NC + y) * NC + x] = out[i];
+      }
+    __syncthreads();
+    // y: lines (x, Z)
+    for (int l = tid; l < NC * NF; l += BLOCK)
+      {
+        const int x = l % NC, Z = l / NC;
+#pragma unroll
+        for (int i = 0; i < NC; ++i)
+          in[i] = buf1[(Z * NC + i) * NC + x];
+        line_embed<T, P, G::BC>(args.E, in, out);
+#pragma unroll
+        for (int i = 0; i < NF; ++i)
+          buf2[(Z * NF + i) * NC + x] = out[i];
+      }
+    __syncthreads();
+    // x: lines (Y, Z)
+    for (int l = tid; l < NF * NF; l += BLOCK)
+      {
+        const int Y = l % NF, Z = l / NF;
+#pragma unroll
+        for (int i = 0; i < NC; ++i)
+          in[i] = buf2[(Z * NF + Y) * NC + i];
+        line_embed<T, P, G::BC>(args.E, in, out);
+#pragma unroll
+        for (int i = 0; i < NF; ++i)
+          bufF[(Z * NF + Y) * NF + i] = out[i];
+      }
+    __syncthreads();
+    // dst += : interior contiguous, then the owned shell
+    if (LG::N_INT > 0)
+      {
+        constexpr int  NI_  = LG::NI > 0 ? LG::NI : 1;
+        constexpr int  NIN_ = LG::N_INT > 0 ? LG::N_INT : 1;
+        constexpr int  ITI  = (NIN_ + BLOCK - 1) / BLOCK;
+        const uint32_t base = args.interior_base[slot];
+        T              val[ITI];
+#pragma unroll
+        for (int it = 0; it < ITI; ++it)
+          {
+            const int i = tid + it * BLOCK;
+            val[it]     = args.dst[base + (i < NIN_ ? i : 0)];
+          }
+#pragma unroll
+        for (int it = 0; it < ITI; ++it)
+          {
+            const int i = tid + it * BLOCK;
+            if (i < NIN_)
+              {
+                const int x = i % NI_, y = (i / NI_) % NI_, z = i / (NI_ * NI_);
+                args.dst[base + i] = val[it] + bufF[((z + 1) * NF + (y + 1)) * NF + x + 1];
+              }
+          }
+      }
+    {
+      constexpr int ITS = (LG::N_SHELL + BLOCK - 1) / BLOCK;
+      uint32_t      gi[ITS];
+      T             val[ITS];
+#pragma unroll
+      for (int it = 0; it < ITS; ++it)
+        {
+          const int s = tid + it * BLOCK;
+          gi[it]      = s < LG::N_SHELL ? args.own_shell[(size_t)brick * LG::N_SHELL + s] : DEV_INVALID;
+        }
+#pragma unroll
+      for (int it = 0; it < ITS; ++it)
+        val[it] = args.dst[gi[it] != DEV_INVALID ? gi[it] : 0];
+#pragma unroll
+      for (int it = 0; it < ITS; ++it)
+        if (gi[it] != DEV_INVALID)
+          args.dst[gi[it]] = val[it] + bufF[args.shell_pos[tid + it * BLOCK]];
+    }
+  }
+
+  template <typename T, int P, int B>
+  __global__ void
+  __launch_bounds__(256) brick_restrict_kernel(const BrickTransferArgs<T, P> args)
+  {
+    using G  = BrickTransferGeo<P, B>;
+    using LG = Geo<P, B>;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    T *bufC = reinterpret_cast<T *>(smem_raw);
+    T *buf1 = bufC + G::NC3;
+    T *buf2 = buf1 + G::S1;
+    T *bufF = buf2 + G::S2;
+    constexpr int NC = G::NC, NF = G::NF, BLOCK = G::BLOCK;
+    const int      tid   = threadIdx.x;
+    const uint32_t brick = blockIdx.x;
+    const uint32_t slot  = args.slot[brick];
+
+    // gather the owned fine residuals (not owned / constrained: 0)
+    if (LG::N_INT > 0)
+      {
+        constexpr int  NI_  = LG::NI > 0 ? LG::NI : 1;
+        constexpr int  NIN_ = LG::N_INT > 0 ? LG::N_INT : 1;
+        constexpr int  ITI  = (NIN_ + BLOCK - 1) / BLOCK;
+        const uint32_t base = args.interior_base[slot];
+        T              val[ITI];
+#pragma unroll
+        for (int it = 0; it < ITI; ++it)
+          {
+            const int i = tid + it * BLOCK;
+            val[it]     = args.src[base + (i < NIN_ ? i : 0)];
+          }
+#pragma unroll
+        for (int it = 0; it < ITI; ++it)
+          {
+            const int i = tid + it * BLOCK;
+            if (i < NIN_)
+              {
+                const int x = i % NI_, y = (i / NI_) % NI_, z = i / (NI_ * NI_);
+                bufF[((z + 1) * NF + (y + 1)) * NF + x + 1] = val[it];
+              }
+          }
+      }
+    {
+      constexpr int ITS = (LG::N_SHELL + BLOCK - 1) / BLOCK;
+      uint32_t      gi[ITS];
+      T             val[ITS];
+#pragma unroll
+      for (int it = 0; it < ITS; ++it)
+        {
+          const int s = tid + it * BLOCK;
+          gi[it]      = s < LG::N_SHELL ? args.own_shell[(size_t)brick * LG::N_SHELL + s] : DEV_INVALID;
+        }
+#pragma unroll
+      for (int it = 0; it < ITS; ++it)
+        val[it] = args.src[gi[it] != DEV_INVALID ? gi[it] : 0];
+#pragma unroll
+      for (int it = 0; it < ITS; ++it)
+        if (tid + it * BLOCK < LG::N_SHELL)
+          bufF[args.shell_pos[tid + it * BLOCK]] = gi[it] != DEV_INVALID ? val[it] : T(0);
+    }
+    __syncthreads();
+    T in[NF], out[NC];
+    // x^T: lines (Y,Z)
+    for (int l = tid; l < NF * NF; l += BLOCK)
+      {
+        const int Y = l % NF, Z = l / NF;
+#pragma unroll
+        for (int i = 0; i < NF; ++i)
+          in[i] = bufF[(Z * NF + Y) * NF + i];
+        line_embed_T<T, P, G::BC>(args.E, in, out);
+#pragma unroll
+        for (int i = 0; i < NC; ++i)
+          buf2[(Z * NF + Y) * NC + i] = out[i];
+      }
+    __syncthreads();
+    // y^T: lines (x, Z)
+    for (int l = tid; l < NC * NF; l += BLOCK)
+      {
+        const int x = l % NC, Z = l / NC;
+#pragma unroll
+        for (int i = 0; i < NF; ++i)
+          in[i] = buf2[(Z * NF + i) * NC + x];
+        line_embed_T<T, P, G::BC>(args.E, in, out);
+#pragma unroll
+        for (int i = 0; i < NC; ++i)
+          buf1[(Z * NC + i) * NC + x] = out[i];
+      }
+    __syncthreads();
+    // z^T: lines (x, y)
+    for (int l = tid; l < NC * NC; l += BLOCK)
+      {
+        const int x = l % NC, y = l / NC;
+#pragma unroll
+        for (int i = 0; i < NF; ++i)
+          in[i] = buf1[(i * NC + y) * NC + x];
+        line_embed_T<T, P, G::BC>(args.E, in, out);
+#pragma unroll
+        for (int i = 0; i < NC; ++i)
+          bufC[(i * NC + y) * NC + x] = out[i];
+      }
+    __syncthreads();
+    {
+      constexpr int ITC = (G::NC3 + BLOCK - 1) / BLOCK;
+      uint32_t      gi[ITC];
+      T             old[ITC];
+      bool          inner[ITC];
+#pragma unroll
+      for (int it = 0; it < ITC; ++it)
+        {
+          const int idx = tid + it * BLOCK;
+          gi[it]        = idx < G::NC3 ? args.coarse_idx[(size_t)brick * G::NC3 + idx] : DEV_INVALID;
+          const int x = idx % NC, y = (idx / NC) % NC, z = idx / (NC * NC);
+          inner[it] = x > 0 && y > 0 && z > 0 && x < NC - 1 && y < NC - 1 && z < NC - 1;
+        }
+#pragma unroll
+      for (int it = 0; it < ITC; ++it)
+        old[it] = args.dst[(gi[it] != DEV_INVALID && inner[it]) ? gi[it] : 0];
+#pragma unroll
+      for (int it = 0; it < ITC; ++it)
+        if (gi[it] != DEV_INVALID)
+          {
+            const T v = bufC[tid + it * BLOCK];
+            if (inner[it])
+              args.dst[gi[it]] = old[it] + v; // only this patch touches coarse nodes strictly inside it
+            else
+              atomic_add(&args.dst[gi[it]], v);
+          }
+    }
+  }
+
+  // ------------------------------------------------------------------------------------------
   // Vector kernels
   // ------------------------------------------------------------------------------------------
   template <typename T>

@@ -744,18 +744,39 @@ namespace mgamd
       DBuf<uint16_t>      coarse_mask;
       std::vector<double> E;
     };
-    GroupD grp[3];
-    int    pc = 1, pf = 1;
-    Ctx   *ctx = nullptr;
-    FE1D   fec;
+    struct BrickD
+    {
+      int            B = 2, fine_group = 0;
+      size_t         n_bricks = 0;
+      DBuf<uint32_t> slot, coarse_idx, own_shell;
+    };
+    GroupD                               grp[3];
+    std::vector<std::unique_ptr<BrickD>> bricks;
+    LevelOperator<T>                    *fop = nullptr;
+    int                                  pc = 1, pf = 1;
+    Ctx                                 *ctx = nullptr;
+    FE1D                                 fec;
 
     Transfer2(LevelOperator<T> *f, LevelOperator<T> *c)
       : fec(c->tables->p)
     {
       fine   = f;
       coarse = c;
+      fop    = f;
       ctx    = f->ctx;
-      TransferTables tt(*f->tables, *c->tables);
+      const char    *nb = getenv("MGAMD_NO_BRICK_TRANSFER");
+      TransferTables tt(*f->tables, *c->tables, !(nb && atoi(nb)));
+      for (const BrickTransferGroup &bg : tt.bricks)
+        {
+          auto d        = std::make_unique<BrickD>();
+          d->B          = bg.B;
+          d->fine_group = bg.fine_group;
+          d->n_bricks   = bg.n_bricks();
+          d->slot.upload(bg.slot);
+          d->coarse_idx.upload(bg.coarse_idx);
+          d->own_shell.upload(bg.own_shell);
+          bricks.push_back(std::move(d));
+        }
       pc = tt.pc;
       pf = tt.pf;
       for (int k = 0; k < 3; ++k)
@@ -805,9 +826,97 @@ namespace mgamd
       HIP_CHECK(hipGetLastError());
     }
 
+    template <int P, int B>
+    void
+    launch_brick(const BrickD &b, const T *src, T *dst, bool prolongate)
+    {
+      using G = BrickTransferGeo<P, B>;
+      BrickTransferArgs<T, P> a;
+      const GroupDev<T>      &fg = *fop->groups[b.fine_group];
+      a.slot          = b.slot.p;
+      a.interior_base = fg.interior_base.p;
+      a.shell_pos     = fg.shell_pos.p;
+      a.coarse_idx    = b.coarse_idx.p;
+      a.own_shell     = b.own_shell.p;
+      a.n_bricks      = (uint32_t)b.n_bricks;
+      const std::vector<double> E = fec.embedding(1, P);
+      for (int i = 0; i < (2 * P + 1) * (P + 1); ++i)
+        a.E[i] = E[i];
+      a.src            = src;
+      a.dst            = dst;
+      const size_t lds = (size_t)G::LDS * sizeof(T);
+      if (prolongate)
+        {
+          auto        kern = brick_prolongate_kernel<T, P, B>;
+          static bool once = false;
+          if (!once)
+            {
+              HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+              once = true;
+            }
+          hipLaunchKernelGGL(kern, (int)b.n_bricks, G::BLOCK, lds, ctx->stream, a);
+        }
+      else
+        {
+          auto        kern = brick_restrict_kernel<T, P, B>;
+          static bool once = false;
+          if (!once)
+            {
+              HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+              once = true;
+            }
+          hipLaunchKernelGGL(kern, (int)b.n_bricks, G::BLOCK, lds, ctx->stream, a);
+        }
+      HIP_CHECK(hipGetLastError());
+    }
+
+    template <int P>
+    void
+    dispatch_brick(const BrickD &b, const T *src, T *dst, bool prolongate)
+    {
+      switch (b.B)
+        {
+          case 2:
+            if constexpr (P * 2 + 1 <= 17)
+              return launch_brick<P, 2>(b, src, dst, prolongate);
+            break;
+          case 4:
+            if constexpr (P * 4 + 1 <= 17)
+              return launch_brick<P, 4>(b, src, dst, prolongate);
+            break;
+          case 8:
+            if constexpr (P * 8 + 1 <= 17)
+              return launch_brick<P, 8>(b, src, dst, prolongate);
+            break;
+          case 16:
+            if constexpr (P * 16 + 1 <= 17)
+              return launch_brick<P, 16>(b, src, dst, prolongate);
+            break;
+        }
+      throw std::runtime_error("brick transfer: unsupported brick size");
+    }
+
     void
     run(const T *src, T *dst, bool prolongate)
     {
+      for (auto &b : bricks)
+        switch (pc)
+          {
+            case 1:
+              dispatch_brick<1>(*b, src, dst, prolongate);
+              break;
+            case 2:
+              dispatch_brick<2>(*b, src, dst, prolongate);
+              break;
+            case 3:
+              dispatch_brick<3>(*b, src, dst, prolongate);
+              break;
+            case 4:
+              dispatch_brick<4>(*b, src, dst, prolongate);
+              break;
+            default:
+              throw std::runtime_error("brick transfer: degree not instantiated");
+          }
       for (int k = 0; k < 3; ++k)
         {
           const GroupD &g = grp[k];

@@ -30,13 +30,30 @@ namespace mgamd
     }
   };
 
+  // h-transfer of a whole fine brick (B^3 cells, lattice Nf = p*B+1) from the (B/2)^3 coarse cells under it
+  // (coarse lattice Nc = p*B/2+1).  The parents of a hanging-node-free brick never carry hanging nodes (all 8
+  // children of a parent lie in the same brick), so no coarse interpolation is needed here.
+  struct BrickTransferGroup
+  {
+    int                   fine_group = 0, B = 2, Nf = 3, Nc = 2;
+    std::vector<uint32_t> slot;        // fine slot index within its group
+    std::vector<uint32_t> coarse_idx;  // per brick x Nc^3 (resolved, INVALID = Dirichlet)
+    std::vector<uint32_t> own_shell;   // per brick x n_shell: fine shell DoF if this brick owns it, else INVALID
+    size_t
+    n_bricks() const
+    {
+      return slot.size();
+    }
+  };
+
   class TransferTables
   {
   public:
-    int           pc = 1, pf = 1;
-    TransferGroup groups[3];
+    int                             pc = 1, pf = 1;
+    TransferGroup                   groups[3];
+    std::vector<BrickTransferGroup> bricks; // only with use_bricks
 
-    TransferTables(const LevelTables &fine, const LevelTables &coarse)
+    TransferTables(const LevelTables &fine, const LevelTables &coarse, bool use_bricks = false)
       : pc(coarse.p)
       , pf(fine.p)
     {
@@ -50,8 +67,73 @@ namespace mgamd
       if (&tf != &tc && pf != pc)
         throw std::runtime_error("transfer: simultaneous h- and p-coarsening is not supported");
       std::vector<bool> claimed(fine.n_dofs, false);
+      std::vector<bool> covered(tc.cells.size(), false); // coarse cells handled by a brick patch
+      if (use_bricks && &tf != &tc && pf == pc)
+        for (size_t gi = 0; gi < fine.groups.size(); ++gi)
+          {
+            const SlotGroup &fg = fine.groups[gi];
+            if (fg.B < 2 || fg.n_slots() == 0)
+              continue;
+            BrickTransferGroup bg;
+            bg.fine_group = (int)gi;
+            bg.B          = fg.B;
+            bg.Nf         = fg.N;
+            bg.Nc         = pc * fg.B / 2 + 1;
+            const int Bc  = fg.B / 2;
+            for (size_t s = 0; s < fg.n_slots(); ++s)
+              {
+                const Cell &fc = tf.cells[fg.first_cell[s]];
+                const Cell  anchor{fc.i & ~(uint32_t)(fg.B - 1), fc.j & ~(uint32_t)(fg.B - 1), fc.k & ~(uint32_t)(fg.B - 1), fc.level};
+                // all parents must be hanging-node-free leaves of the coarse mesh; otherwise (cells not coarsened on
+                // this level, or re-refined by the 2:1 balance) the per-cell patches below take over
+                std::vector<int32_t> parents((size_t)Bc * Bc * Bc, -1);
+                bool                 ok = true;
+                for (int cz = 0; ok && cz < Bc; ++cz)
+                  for (int cy = 0; ok && cy < Bc; ++cy)
+                    for (int cx = 0; ok && cx < Bc; ++cx)
+                      {
+                        const int32_t *par = tc.index.find(cell_key(anchor.level - 1, (anchor.i >> 1) + cx, (anchor.j >> 1) + cy, (anchor.k >> 1) + cz));
+                        if (!par || (tc.masks[*par] >> MASK_FACE_SHIFT))
+                          ok = false;
+                        else
+                          parents[(cz * Bc + cy) * Bc + cx] = *par;
+                      }
+                if (!ok)
+                  continue;
+                bg.slot.push_back((uint32_t)s);
+                for (int32_t par : parents)
+                  covered[par] = true;
+                for (int Z = 0; Z < bg.Nc; ++Z)
+                  for (int Y = 0; Y < bg.Nc; ++Y)
+                    for (int X = 0; X < bg.Nc; ++X)
+                      {
+                        const int c[3] = {std::min(X / pc, Bc - 1), std::min(Y / pc, Bc - 1), std::min(Z / pc, Bc - 1)};
+                        const int l[3] = {X - c[0] * pc, Y - c[1] * pc, Z - c[2] * pc};
+                        bg.coarse_idx.push_back(coarse.cell_node_index((size_t)parents[(c[2] * Bc + c[1]) * Bc + c[0]], l));
+                      }
+                // interior DoFs are owned by construction; claim the free shell DoFs nobody owns yet
+                for (int t = 0; t < fg.n_interior; ++t)
+                  claimed[fg.interior_base[s] + t] = true;
+                for (int t = 0; t < fg.n_shell; ++t)
+                  {
+                    uint32_t idx = fg.shell_idx[s * fg.n_shell + t];
+                    if (idx != INVALID_DOF)
+                      {
+                        if (claimed[idx])
+                          idx = INVALID_DOF;
+                        else
+                          claimed[idx] = true;
+                      }
+                    bg.own_shell.push_back(idx);
+                  }
+              }
+            if (bg.n_bricks())
+              bricks.push_back(std::move(bg));
+          }
       for (size_t ci = 0; ci < tc.cells.size(); ++ci)
         {
+          if (covered[ci])
+            continue;
           const Cell    &cc = tc.cells[ci];
           const int32_t *same = tf.index.find(cell_key(cc));
           int            kind;
