@@ -25,7 +25,7 @@ $(LIBDIR)/c_api_host.o: $(CSRC)/c_api_host.cpp $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
 
 $(LIB): $(LIBDIR)/runtime.o $(LIBDIR)/c_api_device.o $(LIBDIR)/c_api_host.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -L/opt/rocm/lib -lrccl
 
 $(BIN): dealii_multigrid_amd/harness/multigrid_throughput.cpp $(CSRC)/mgamd.hpp include/mgamd.h $(LIB)
 	@mkdir -p dealii_multigrid_amd/bin

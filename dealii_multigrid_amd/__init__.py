@@ -68,6 +68,11 @@ class DofsInfo(C.Structure):
         ("n_groups", C.c_uint32),
         ("group_B", C.c_uint32 * 8),
         ("group_slots", C.c_uint64 * 8),
+        ("n_tail_owned", C.c_uint32),
+        ("n_dirichlet_owned", C.c_uint32),
+        ("n_hanging_owned", C.c_uint32),
+        ("n_peers", C.c_uint32),
+        ("n_halo_send", C.c_uint32),
     ]
 
 
@@ -121,11 +126,37 @@ def create_polynomial_coarsening_sequence(degree: int):
     return seq[::-1]
 
 
+class Partition:
+    """Domain decomposition of a level hierarchy over n_ranks GPUs."""
+
+    def __init__(self, trias, n_ranks: int, hanging_weight: float = 2.0):
+        self.trias, self.n_ranks = list(trias), n_ranks
+        arr = (C.c_void_p * len(self.trias))(*[t._h for t in self.trias])
+        self._h = C.c_void_p()
+        _chk(_lib.mgamd_partition_create(arr, len(self.trias), n_ranks, C.c_double(hanging_weight), C.byref(self._h)))
+        rl = C.c_uint()
+        _chk(_lib.mgamd_partition_info(self._h, C.byref(rl), None))
+        self.root_level = rl.value
+
+    def owner(self, level: int):
+        o = np.zeros(self.trias[level].n_cells, np.uint16)
+        _chk(_lib.mgamd_partition_get_owner(self._h, level, _ptr(o)))
+        return o
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.mgamd_partition_destroy(self._h)
+            self._h = None
+
+
 class DoFs:
-    def __init__(self, tria: Triangulation, degree: int, max_brick: int = 0):
+    def __init__(self, tria: Triangulation, degree: int, max_brick: int = 0, partition: "Partition" = None, level: int = 0, rank: int = 0):
         self.tria = tria
         self._h = C.c_void_p()
-        _chk(_lib.mgamd_dofs_create(tria._h, degree, max_brick, C.byref(self._h)))
+        if partition is None:
+            _chk(_lib.mgamd_dofs_create(tria._h, degree, max_brick, C.byref(self._h)))
+        else:
+            _chk(_lib.mgamd_dofs_create_local(partition._h, level, rank, degree, max_brick, C.byref(self._h)))
         self.info = DofsInfo()
         _chk(_lib.mgamd_dofs_info(self._h, C.byref(self.info)))
         self.degree = degree
@@ -200,6 +231,52 @@ class Context:
             self._h = None
 
 
+class SimGroup:
+    """In-process simulation of n ranks on one GPU (every rank is a host thread); for tests."""
+
+    def __init__(self, n_ranks: int):
+        self.n_ranks = n_ranks
+        self._h = C.c_void_p()
+        _chk(_lib.mgamd_sim_group_create(n_ranks, C.byref(self._h)))
+
+    def comm(self, rank: int) -> "Communicator":
+        h = C.c_void_p()
+        _chk(_lib.mgamd_comm_sim_create(self._h, rank, C.byref(h)))
+        return Communicator(h, self.n_ranks, rank, self)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.mgamd_sim_group_destroy(self._h)
+            self._h = None
+
+
+class Communicator:
+    def __init__(self, handle, n_ranks, rank, keepalive=None):
+        self._h, self.n_ranks, self.rank, self._keep = handle, n_ranks, rank, keepalive
+
+    @staticmethod
+    def rccl_unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        _chk(_lib.mgamd_comm_rccl_unique_id(buf))
+        return buf.raw
+
+    @staticmethod
+    def rccl(ctx: "Context", n_ranks: int, rank: int, unique_id: bytes) -> "Communicator":
+        h = C.c_void_p()
+        _chk(_lib.mgamd_comm_rccl_create(ctx._h, n_ranks, rank, C.c_char_p(unique_id), C.byref(h)))
+        return Communicator(h, n_ranks, rank)
+
+    def allreduce_sum(self, ctx: "Context", value: float) -> float:
+        r = C.c_double()
+        _chk(_lib.mgamd_comm_allreduce_sum(self._h, ctx._h, C.c_double(value), C.byref(r)))
+        return r.value
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.mgamd_comm_destroy(self._h)
+            self._h = None
+
+
 class Vector:
     """LinearAlgebra::distributed::Vector<Number>, device resident."""
 
@@ -253,10 +330,23 @@ class Vector:
 class Operator:
     """Operator<3,1,Number> (ref:include/operator.h:11-557)."""
 
-    def __init__(self, ctx: Context, dofs: DoFs, number_type: int = F64):
-        self.ctx, self.dofs, self.number_type = ctx, dofs, number_type
+    def __init__(self, ctx: Context, dofs: DoFs, number_type: int = F64, comm: "Communicator" = None):
+        self.ctx, self.dofs, self.number_type, self.comm = ctx, dofs, number_type, comm
         self._h = C.c_void_p()
-        _chk(_lib.mgamd_level_op_create(ctx._h, dofs._h, number_type, C.byref(self._h)))
+        if comm is None:
+            _chk(_lib.mgamd_level_op_create(ctx._h, dofs._h, number_type, C.byref(self._h)))
+        else:
+            _chk(_lib.mgamd_level_op_create_distributed(ctx._h, dofs._h, number_type, comm._h, C.byref(self._h)))
+
+    def dot(self, x: "Vector", y: "Vector") -> float:
+        r = C.c_double()
+        _chk(_lib.mgamd_level_op_dot(self._h, x._h, y._h, C.byref(r)))
+        return r.value
+
+    def n_owned(self) -> int:
+        n = C.c_uint64()
+        _chk(_lib.mgamd_level_op_n_owned(self._h, C.byref(n)))
+        return n.value
 
     def m(self) -> int:
         n = C.c_uint64()
@@ -396,3 +486,25 @@ class Hierarchy:
         self.mg = PreconditionMG(ctx, self.operators, self.transfers, self.smoothers, coarse_solver)
         self.fine_operator = self.operators[-1] if number_type == F64 else Operator(ctx, self.dofs[-1], F64)
         self.n_dofs = self.dofs[-1].n_dofs
+
+
+class DistributedHierarchy:
+    """One rank's share of the hierarchy: levels below the partition's root level are replicated, the others hold this
+    rank's cells and exchange the partial sums of shared DoFs through `comm` (RCCL over xGMI in production)."""
+
+    def __init__(self, ctx: Context, comm: Communicator, geometry="quadrant", n_ref_global=3, degree=1, smoother_degree=3,
+                 smoothing_range=20.0, eig_cg_n_iterations=20, coarse_solver="amg", number_type=F64, hanging_weight=2.0, max_brick=0):
+        self.ctx, self.comm = ctx, comm
+        fine = Triangulation(geometry, n_ref_global)
+        self.trias = create_geometric_coarsening_sequence(fine)
+        self.partition = Partition(self.trias, comm.n_ranks, hanging_weight)
+        nl = len(self.trias)
+        self.dofs = [DoFs(self.trias[l], degree, max_brick, self.partition, l, comm.rank) for l in range(nl)]
+        self.operators = [Operator(ctx, self.dofs[l], number_type, comm if l >= self.partition.root_level and comm.n_ranks > 1 else None)
+                          for l in range(nl)]
+        self.transfers = [None] + [MGTwoLevelTransfer(self.operators[l], self.operators[l - 1]) for l in range(1, nl)]
+        self.smoothers = [PreconditionChebyshev(op, smoother_degree, smoothing_range, eig_cg_n_iterations) for op in self.operators]
+        self.mg = PreconditionMG(ctx, self.operators, self.transfers, self.smoothers, coarse_solver)
+        self.fine_operator = self.operators[-1]
+        self.n_local = self.dofs[-1].n_dofs
+        self.n_dofs = int(round(comm.allreduce_sum(ctx, float(self.fine_operator.n_owned()))))

@@ -3,6 +3,7 @@
 #include "../../include/mgamd.h"
 #include "level_tables.hpp"
 #include "transfer_tables.hpp"
+#include "partition.hpp"
 
 #include <memory>
 #include <string>
@@ -26,6 +27,17 @@ struct mgamd_dofs
 {
   std::shared_ptr<mgamd::Tria>        tria; // keeps the mesh alive
   std::shared_ptr<mgamd::LevelTables> tables;
+  // distributed levels only
+  std::shared_ptr<std::vector<uint8_t>>         owned;
+  std::shared_ptr<std::map<uint64_t, mgamd::SharedInfo>> shared;
+  std::shared_ptr<mgamd::HaloPlan>              halo;
+  int                                           n_ranks = 1, rank = 0;
+};
+
+struct mgamd_partition
+{
+  std::vector<std::shared_ptr<mgamd::Tria>> trias; // coarse -> fine
+  mgamd::Partition                          part;
 };
 
 #define MGAMD_TRY \

@@ -190,6 +190,124 @@ mgamd_level_op_create(mgamd_ctx *ctx, const mgamd_dofs *dofs, int number_type, m
 }
 
 int
+mgamd_level_op_create_distributed(mgamd_ctx *ctx, const mgamd_dofs *dofs, int number_type, mgamd_comm *comm, mgamd_level_op **out)
+{
+  MGAMD_TRY
+  REQUIRE(ctx && dofs && out);
+  if (dofs->halo && !comm)
+    throw std::invalid_argument("a distributed level needs a communicator");
+  auto *h = new mgamd_level_op;
+  try
+    {
+      h->op.reset(make_level_operator(ctx->ctx.get(), dofs, number_type, comm ? comm->comm : nullptr));
+    }
+  catch (...)
+    {
+      delete h;
+      throw;
+    }
+  *out = h;
+  MGAMD_CATCH
+}
+
+int
+mgamd_level_op_dot(mgamd_level_op *op, const mgamd_vec *x, const mgamd_vec *y, double *result)
+{
+  MGAMD_TRY
+  REQUIRE(op && x && y && result);
+  *result = op->op->dot(*x, *y);
+  MGAMD_CATCH
+}
+
+int
+mgamd_level_op_n_owned(const mgamd_level_op *op, uint64_t *n)
+{
+  MGAMD_TRY
+  REQUIRE(op && n);
+  *n = op->op->comm ? op->op->n_dofs_owned() : op->op->n_dofs();
+  MGAMD_CATCH
+}
+
+int
+mgamd_comm_rccl_unique_id(char id[128])
+{
+  MGAMD_TRY
+  REQUIRE(id);
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+  ncclUniqueId u;
+  RcclComm::check(ncclGetUniqueId(&u), "ncclGetUniqueId");
+  std::memcpy(id, &u, 128);
+  MGAMD_CATCH
+}
+
+int
+mgamd_comm_rccl_create(mgamd_ctx *ctx, unsigned n_ranks, unsigned rank, const char id[128], mgamd_comm **out)
+{
+  MGAMD_TRY
+  REQUIRE(ctx && id && out && rank < n_ranks);
+  HIP_CHECK(hipSetDevice(ctx->ctx->device));
+  ncclUniqueId u;
+  std::memcpy(&u, id, 128);
+  auto *c = new mgamd_comm;
+  try
+    {
+      c->comm = std::make_shared<RcclComm>((int)n_ranks, (int)rank, u);
+    }
+  catch (...)
+    {
+      delete c;
+      throw;
+    }
+  *out = c;
+  MGAMD_CATCH
+}
+
+int
+mgamd_sim_group_create(unsigned n_ranks, mgamd_sim_group **out)
+{
+  MGAMD_TRY
+  REQUIRE(out && n_ranks > 0);
+  auto *g  = new mgamd_sim_group;
+  g->group = std::make_shared<SimGroup>((int)n_ranks);
+  *out     = g;
+  MGAMD_CATCH
+}
+
+int
+mgamd_sim_group_destroy(mgamd_sim_group *g)
+{
+  delete g;
+  return MGAMD_OK;
+}
+
+int
+mgamd_comm_sim_create(mgamd_sim_group *g, unsigned rank, mgamd_comm **out)
+{
+  MGAMD_TRY
+  REQUIRE(g && out && (int)rank < g->group->n);
+  auto *c = new mgamd_comm;
+  c->comm = std::make_shared<SimComm>(g->group, (int)rank);
+  *out    = c;
+  MGAMD_CATCH
+}
+
+int
+mgamd_comm_destroy(mgamd_comm *c)
+{
+  delete c;
+  return MGAMD_OK;
+}
+
+int
+mgamd_comm_allreduce_sum(mgamd_comm *c, mgamd_ctx *ctx, double value, double *result)
+{
+  MGAMD_TRY
+  REQUIRE(c && ctx && result);
+  *result = c->comm->allreduce_sum_host(value, ctx->ctx->stream);
+  MGAMD_CATCH
+}
+
+int
 mgamd_level_op_destroy(mgamd_level_op *op)
 {
   delete op;

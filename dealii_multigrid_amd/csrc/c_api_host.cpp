@@ -129,6 +129,11 @@ mgamd_dofs_info(const mgamd_dofs *d, mgamd_dofs_info_t *info)
   info->n_dirichlet = L.n_dirichlet;
   info->n_hanging   = L.n_hanging;
   info->n_groups    = (uint32_t)L.groups.size();
+  info->n_tail_owned      = L.n_tail_owned;
+  info->n_dirichlet_owned = L.n_dirichlet_owned;
+  info->n_hanging_owned   = L.n_hanging_owned;
+  info->n_peers           = d->halo ? (uint32_t)d->halo->peers.size() : 0;
+  info->n_halo_send       = d->halo ? (uint32_t)d->halo->pack_idx.size() : 0;
   for (size_t g = 0; g < L.groups.size() && g < 8; ++g)
     {
       info->group_B[g]     = L.groups[g].B;
@@ -171,6 +176,101 @@ mgamd_dofs_rhs_constant(const mgamd_dofs *d, double *out)
   std::vector<double> b;
   d->tables->compute_rhs_constant(b);
   std::memcpy(out, b.data(), b.size() * sizeof(double));
+  MGAMD_CATCH
+}
+
+int
+mgamd_partition_create(const mgamd_tria *const *trias, unsigned n_levels, unsigned n_ranks, double hanging_weight, mgamd_partition **out)
+{
+  MGAMD_TRY
+  if (!trias || !out || n_levels == 0 || n_ranks == 0)
+    throw std::invalid_argument("bad argument");
+  auto                     *p = new mgamd_partition;
+  std::vector<const Tria *> raw;
+  for (unsigned l = 0; l < n_levels; ++l)
+    {
+      if (!trias[l])
+        throw std::invalid_argument("null triangulation");
+      p->trias.push_back(trias[l]->tria);
+      raw.push_back(trias[l]->tria.get());
+    }
+  try
+    {
+      p->part = make_partition(raw, (int)n_ranks, hanging_weight);
+    }
+  catch (...)
+    {
+      delete p;
+      throw;
+    }
+  *out = p;
+  MGAMD_CATCH
+}
+
+int
+mgamd_partition_destroy(mgamd_partition *p)
+{
+  delete p;
+  return MGAMD_OK;
+}
+
+int
+mgamd_partition_info(const mgamd_partition *p, unsigned *root_level, unsigned *n_ranks)
+{
+  MGAMD_TRY
+  if (!p)
+    throw std::invalid_argument("null argument");
+  if (root_level)
+    *root_level = (unsigned)p->part.root_level;
+  if (n_ranks)
+    *n_ranks = (unsigned)p->part.n_ranks;
+  MGAMD_CATCH
+}
+
+int
+mgamd_partition_get_owner(const mgamd_partition *p, unsigned level, uint16_t *owner)
+{
+  MGAMD_TRY
+  if (!p || !owner || level >= p->trias.size() || (int)level < p->part.root_level)
+    throw std::invalid_argument("bad argument");
+  const auto &o = p->part.level_owner((int)level);
+  std::memcpy(owner, o.data(), o.size() * sizeof(uint16_t));
+  MGAMD_CATCH
+}
+
+int
+mgamd_dofs_create_local(const mgamd_partition *p, unsigned level, unsigned rank, int degree, int max_brick, mgamd_dofs **out)
+{
+  MGAMD_TRY
+  if (!p || !out || level >= p->trias.size() || (int)rank >= p->part.n_ranks)
+    throw std::invalid_argument("bad argument");
+  if (degree < 1 || degree > MAX_DEGREE)
+    throw std::invalid_argument("degree must be in [1," + std::to_string(MAX_DEGREE) + "]");
+  auto *d    = new mgamd_dofs;
+  d->tria    = p->trias[level];
+  d->n_ranks = p->part.n_ranks;
+  d->rank    = (int)rank;
+  try
+    {
+      if (p->part.replicated((int)level) || p->part.n_ranks == 1)
+        d->tables = std::make_shared<LevelTables>(*d->tria, degree, max_brick);
+      else
+        {
+          const auto &owner = p->part.level_owner((int)level);
+          d->owned          = std::make_shared<std::vector<uint8_t>>(owner.size());
+          for (size_t c = 0; c < owner.size(); ++c)
+            (*d->owned)[c] = owner[c] == rank;
+          d->shared = std::make_shared<std::map<uint64_t, SharedInfo>>(shared_keys(*d->tria, owner, p->part.n_ranks, (int)rank, degree));
+          d->tables = std::make_shared<LevelTables>(*d->tria, degree, max_brick, d->owned.get(), false, d->shared.get(), (int)rank);
+          d->halo   = std::make_shared<HaloPlan>(make_halo_plan(*d->tables, *d->shared, p->part.n_ranks, (int)rank));
+        }
+    }
+  catch (...)
+    {
+      delete d;
+      throw;
+    }
+  *out = d;
   MGAMD_CATCH
 }
 

@@ -1259,6 +1259,52 @@ namespace mgamd
   }
 
   // ------------------------------------------------------------------------------------------
+  // Halo exchange of shared tail DoFs (sharded runs): pack the partial sums per peer, and after the exchange
+  // combine own + received contributions in ascending rank order (bitwise identical on every sharing rank).
+  // ------------------------------------------------------------------------------------------
+  template <typename T>
+  __global__ void
+  __launch_bounds__(256) halo_pack_kernel(T *__restrict__ send, const T *__restrict__ tail, const uint32_t *__restrict__ pack_idx, uint32_t n)
+  {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+      send[i] = tail[pack_idx[i]];
+  }
+
+  template <typename T>
+  __global__ void
+  __launch_bounds__(256) halo_combine_kernel(T *__restrict__ tail, const T *__restrict__ recv, const uint32_t *__restrict__ sh_tail,
+                                             const uint32_t *__restrict__ sh_ptr, const int32_t *__restrict__ sh_src, uint32_t n_shared)
+  {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_shared; i += stride)
+      {
+        const uint32_t t   = sh_tail[i];
+        const T        own = tail[t];
+        T              acc = T(0);
+        for (uint32_t e = sh_ptr[i]; e < sh_ptr[i + 1]; ++e)
+          {
+            const int32_t src = sh_src[e];
+            acc += src < 0 ? own : recv[src];
+          }
+        tail[t] = acc;
+      }
+  }
+
+  // copies of shared DoFs take the owner's value (after prolongation: ranks that reference a coarse face only through
+  // hanging-node resolution have no patch that writes their copy)
+  template <typename T>
+  __global__ void
+  __launch_bounds__(256) halo_import_kernel(T *__restrict__ tail, const T *__restrict__ recv, const uint32_t *__restrict__ sh_tail,
+                                            const int32_t *__restrict__ sh_owner_src, uint32_t n_shared)
+  {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_shared; i += stride)
+      if (sh_owner_src[i] >= 0)
+        tail[sh_tail[i]] = recv[sh_owner_src[i]];
+  }
+
+  // ------------------------------------------------------------------------------------------
   // Vector kernels
   // ------------------------------------------------------------------------------------------
   template <typename T>

@@ -21,6 +21,24 @@
 #include "fe1d.hpp"
 #include "octree.hpp"
 
+#include <map>
+
+namespace mgamd
+{
+  // sharded runs: who else references a DoF on an inter-rank interface (see partition.hpp)
+  struct SharedInfo
+  {
+    uint64_t others  = 0; // other ranks referencing the DoF
+    uint64_t regular = 0; // ranks (including this one) referencing it as a node of one of their own cells
+  };
+  // the owner is the lowest rank among the regular referencers: it is guaranteed to have a transfer patch for the DoF
+  inline int
+  shared_owner(const SharedInfo &si)
+  {
+    return __builtin_ctzll(si.regular);
+  }
+} // namespace mgamd
+
 namespace mgamd
 {
   constexpr uint32_t INVALID_DOF = 0xFFFFFFFFu;
@@ -139,17 +157,30 @@ namespace mgamd
     FE1D                   fe;
     std::vector<SlotGroup> groups; // one per brick size, largest first; last = single cells
     uint32_t               n_dofs = 0, n_interior = 0, n_tail = 0, n_dirichlet = 0, n_hanging = 0;
+    // distributed runs: the tail is [owned | copies of DoFs owned by a lower rank]; *_owned count each DoF once globally
+    uint32_t n_tail_owned = 0, n_dirichlet_owned = 0, n_hanging_owned = 0;
     // per cell: group, slot-in-group
     std::vector<uint8_t>  cell_group;
     std::vector<uint32_t> cell_slot;
     FlatMap               keymap; // packed key -> global index (T, D, H DoFs only)
 
-    LevelTables(const Tria &t, int degree, int max_brick = 0)
+    // owned: optional per-cell flags (distributed runs: this rank's cells); shared: key -> mask of other sharing ranks
+    LevelTables(const Tria &t, int degree, int max_brick = 0, const std::vector<uint8_t> *owned = nullptr, bool helpers_only = false,
+                const std::map<uint64_t, SharedInfo> *shared = nullptr, int my_rank = 0)
       : p(degree)
       , tria(&t)
       , fe(degree)
+      , owned(owned)
+      , shared(shared)
+      , my_rank(my_rank)
     {
-      build(max_brick > 0 ? std::min(max_brick, max_brick_for_degree(p)) : max_brick_for_degree(p));
+      if (!helpers_only)
+        build(max_brick > 0 ? std::min(max_brick, max_brick_for_degree(p)) : max_brick_for_degree(p));
+    }
+    bool
+    cell_is_local(size_t ci) const
+    {
+      return cell_group[ci] < 0xFE;
     }
 
     uint32_t
@@ -208,6 +239,14 @@ namespace mgamd
     uint32_t
     cell_node_index(size_t ci, const int a[3], bool *constrained = nullptr, bool *parent_corner = nullptr) const
     {
+      if (!cell_is_local(ci))
+        {
+          if (constrained)
+            *constrained = false;
+          if (parent_corner)
+            *parent_corner = false;
+          return INVALID_DOF;
+        }
       const SlotGroup &g    = groups[cell_group[ci]];
       const uint32_t   s    = cell_slot[ci];
       const Cell      &c    = tria->cells[ci];
@@ -312,8 +351,11 @@ namespace mgamd
     }
 
   private:
-    std::vector<uint64_t> key_list;  // keys of T/D/H DoFs in creation order
-    std::vector<int32_t>  key_index; // their final global indices
+    std::vector<uint64_t>               key_list;  // keys of T/D/H DoFs in creation order
+    std::vector<int32_t>                key_index; // their final global indices
+    const std::vector<uint8_t>         *owned   = nullptr;
+    const std::map<uint64_t, SharedInfo> *shared  = nullptr;
+    int                                 my_rank = 0;
 
     void
     build(int Bmax)
@@ -328,6 +370,10 @@ namespace mgamd
       groups.resize(sizes.size());
       cell_group.assign(nc, 0xFF);
       cell_slot.assign(nc, 0);
+      if (owned)
+        for (size_t t = 0; t < nc; ++t)
+          if (!(*owned)[t])
+            cell_group[t] = 0xFE; // not ours
       for (size_t gi = 0; gi < sizes.size(); ++gi)
         {
           SlotGroup &g = groups[gi];
@@ -408,12 +454,26 @@ namespace mgamd
       n_interior = (uint32_t)next;
       // ---- 3. shell DoFs: class 0 tail, 1 Dirichlet, 2 hanging; provisional id = (class<<30 | counter)
       keymap.erase_all_and_reserve(1024);
-      uint32_t counter[3] = {0, 0, 0};
-      auto     classify   = [&](uint64_t key, int cls) -> int32_t {
+      uint32_t counter[4] = {0, 0, 0, 0}; // 0 tail (owned), 1 Dirichlet, 2 hanging, 3 tail copy of a lower rank's DoF
+      uint32_t n_copy_d = 0, n_copy_h = 0;
+      auto     classify = [&](uint64_t key, int cls) -> int32_t {
         bool     ins;
         int32_t *v = keymap.insert(key, 0, &ins);
         if (ins)
           {
+            if (shared)
+              {
+                auto it = shared->find(key);
+                if (it != shared->end() && shared_owner(it->second) != my_rank)
+                  { // another rank owns this DoF (the lowest rank that references it as a node of one of its cells)
+                    if (cls == 0)
+                      cls = 3;
+                    else if (cls == 1)
+                      ++n_copy_d;
+                    else
+                      ++n_copy_h;
+                  }
+              }
             *v = (int32_t)(((uint32_t)cls << 30) | counter[cls]++);
             key_list.push_back(key);
           }
@@ -456,14 +516,17 @@ namespace mgamd
                     }
             }
       }
-      n_tail      = counter[0];
-      n_dirichlet = counter[1];
-      n_hanging   = counter[2];
+      n_tail_owned      = counter[0];
+      n_tail            = counter[0] + counter[3];
+      n_dirichlet       = counter[1];
+      n_hanging         = counter[2];
+      n_dirichlet_owned = n_dirichlet - n_copy_d;
+      n_hanging_owned   = n_hanging - n_copy_h;
       const uint64_t total = (uint64_t)n_interior + n_tail + n_dirichlet + n_hanging;
       if (total > 0xFFFFFFF0ull)
         throw std::runtime_error("level exceeds 32-bit DoF indices");
       n_dofs                 = (uint32_t)total;
-      const uint32_t base[3] = {n_interior, n_interior + n_tail, n_interior + n_tail + n_dirichlet};
+      const uint32_t base[4] = {n_interior, n_interior + n_tail, n_interior + n_tail + n_dirichlet, n_interior + n_tail_owned};
       auto           final_index = [&](uint32_t prov) { return base[prov >> 30] + (prov & 0x3FFFFFFFu); };
       key_index.resize(key_list.size());
       for (size_t t = 0; t < key_list.size(); ++t)

@@ -1,0 +1,283 @@
+// Spatial domain decomposition of the level hierarchy for one rank per GPU (the reference
+// partitions with p4est + RepartitioningPolicyTools, ref:multigrid_throughput.cc:2066-2175,2219-2224).
+//
+//  * One ROOT level l_r is chosen (first level with enough cells per rank).  Its leaves are cut, in Morton order,
+//    into n_ranks contiguous chunks of equal weight (weight = number of finest-level leaves below a root cell,
+//    hanging-node cells weighted like ref:multigrid_throughput.cc:283-291 `CellWeightPolicy`).
+//  * Every cell of a finer level belongs to the rank of its root-level ancestor, so a cell and its parent are always
+//    on the same rank (the idea of the reference's FirstChildPolicy, ref:multigrid_throughput.cc:2156-2170): all
+//    level transfers above the root level are rank-local.
+//  * Levels below the root level are REPLICATED on every rank (they are tiny); the restriction onto the first
+//    replicated level is completed by one all-reduce.
+//  * DoFs on inter-rank interfaces exist as consistent copies on every sharing rank; partial sums are exchanged
+//    symmetrically between the sharers and summed in ascending rank order, so all copies stay bitwise identical.
+//    Which DoFs rank q shares is computed from the replicated mesh without communication: the keys referenced by q's
+//    cells that have a foreign leaf in their 26-neighbourhood (candidate set); shared(r,q) = cand(r) n cand(q).
+#pragma once
+#include "level_tables.hpp"
+
+#include <map>
+
+namespace mgamd
+{
+  struct Partition
+  {
+    int                                n_ranks = 1;
+    int                                root_level = 0;               // index into the level list (coarse -> fine)
+    std::vector<std::vector<uint16_t>> owner;                        // per level >= root_level: owner of each cell
+    const std::vector<uint16_t> &
+    level_owner(int level) const
+    {
+      return owner[level - root_level];
+    }
+    bool
+    replicated(int level) const
+    {
+      return level < root_level;
+    }
+  };
+
+  inline Partition
+  make_partition(const std::vector<const Tria *> &trias, int n_ranks, double hanging_weight = 2.0, size_t min_cells_per_rank = 32)
+  {
+    Partition P;
+    P.n_ranks       = n_ranks;
+    const int nl    = (int)trias.size();
+    int       root  = nl - 1;
+    for (int l = 1; l < nl; ++l)
+      if (trias[l]->n_cells() >= min_cells_per_rank * (size_t)n_ranks)
+        {
+          root = l;
+          break;
+        }
+    if (root < 1)
+      root = std::min(1, nl - 1);
+    P.root_level   = root;
+    const Tria &tr = *trias[root];
+    const Tria &tf = *trias[nl - 1];
+    // weights of the root cells
+    std::vector<double> w(tr.n_cells(), 0.0);
+    for (size_t c = 0; c < tf.n_cells(); ++c)
+      {
+        const Cell &fc  = tf.cells[c];
+        const int   anc = tr.find_leaf(fc.level, fc.i, fc.j, fc.k);
+        if (anc < 0)
+          throw std::runtime_error("partition: level meshes are not nested");
+        w[anc] += (tf.masks[c] >> MASK_FACE_SHIFT) ? hanging_weight : 1.0;
+      }
+    double total = 0;
+    for (double x : w)
+      total += x;
+    std::vector<uint16_t> root_owner(tr.n_cells());
+    double                acc = 0;
+    for (size_t c = 0; c < tr.n_cells(); ++c)
+      {
+        const double mid = acc + 0.5 * w[c];
+        int          r   = (int)(mid / total * n_ranks);
+        root_owner[c]    = (uint16_t)std::min(std::max(r, 0), n_ranks - 1);
+        acc += w[c];
+      }
+    P.owner.resize(nl - root);
+    P.owner[0] = root_owner;
+    for (int l = root + 1; l < nl; ++l)
+      {
+        const Tria &t = *trias[l];
+        auto       &o = P.owner[l - root];
+        o.resize(t.n_cells());
+        for (size_t c = 0; c < t.n_cells(); ++c)
+          {
+            const Cell &fc  = t.cells[c];
+            const int   anc = tr.find_leaf(fc.level, fc.i, fc.j, fc.k);
+            if (anc < 0)
+              throw std::runtime_error("partition: level meshes are not nested");
+            o[c] = root_owner[anc];
+          }
+      }
+    return P;
+  }
+
+  // Keys referenced by the cells of `rank` that have a leaf of another rank in their 26-neighbourhood, sorted by key.
+  // The flag byte holds the class (bits 0-1: 0 unconstrained, 1 Dirichlet, 2 hanging-own) and bit 7 = REGULAR: the key
+  // is a node of one of those cells itself (not only reached through hanging-node resolution to a parent entity).
+  // Only regular referencers can own a shared DoF: they are the ranks that have a transfer patch writing/reading it.
+  inline std::vector<std::pair<uint64_t, uint8_t>>
+  interface_candidate_keys(const Tria &tria, const std::vector<uint16_t> &owner, int rank, int p)
+  {
+    std::vector<std::pair<uint64_t, uint8_t>> out;
+    LevelTables                               probe(tria, p, 1, nullptr, /*tables_only_helpers=*/true);
+    const int                                 n = p + 1;
+    for (size_t ci = 0; ci < tria.n_cells(); ++ci)
+      {
+        if (owner[ci] != rank)
+          continue;
+        const Cell &c       = tria.cells[ci];
+        bool        foreign = false;
+        // neighbourhood at the cell's own level, at the parent's level (coarser neighbours) and the children's level
+        for (int dz = -1; dz <= 1 && !foreign; ++dz)
+          for (int dy = -1; dy <= 1 && !foreign; ++dy)
+            for (int dx = -1; dx <= 1 && !foreign; ++dx)
+              {
+                if (!dx && !dy && !dz)
+                  continue;
+                const int nb = tria.find_leaf(c.level, (int64_t)c.i + dx, (int64_t)c.j + dy, (int64_t)c.k + dz);
+                if (nb >= 0)
+                  {
+                    if (owner[nb] != rank)
+                      foreign = true;
+                  }
+                else
+                  {
+                    // region is outside the domain or covered by finer leaves: probe the 8 children positions
+                    const int64_t bi = 2 * ((int64_t)c.i + dx), bj = 2 * ((int64_t)c.j + dy), bk = 2 * ((int64_t)c.k + dz);
+                    for (int t = 0; t < 8 && !foreign; ++t)
+                      {
+                        const int f = tria.find_leaf(c.level + 1, bi + (t & 1), bj + ((t >> 1) & 1), bk + (t >> 2));
+                        if (f >= 0 && owner[f] != rank)
+                          foreign = true;
+                      }
+                  }
+              }
+        if (!foreign)
+          continue;
+        const uint16_t mask = tria.masks[ci];
+        for (int z = 0; z < n; ++z)
+          for (int y = 0; y < n; ++y)
+            for (int x = 0; x < n; ++x)
+              {
+                const int      a[3] = {x, y, z};
+                const uint64_t key  = probe.resolved_key(ci, a);
+                bool           corner = false;
+                const bool     via_parent =
+                  (mask >> MASK_FACE_SHIFT) && LevelTables::node_on_constrained_entity(mask, p, a, &corner) && !corner;
+                out.push_back({key, (uint8_t)((probe.key_on_boundary(key) ? 1 : 0) | (via_parent ? 0 : 0x80))});
+                if (via_parent)
+                  out.push_back({probe.own_key(c, a), (uint8_t)(2 | 0x80)});
+              }
+      }
+    std::sort(out.begin(), out.end());
+    // merge duplicates: a key is regular if any reference is
+    std::vector<std::pair<uint64_t, uint8_t>> merged;
+    for (const auto &e : out)
+      if (!merged.empty() && merged.back().first == e.first)
+        merged.back().second |= e.second;
+      else
+        merged.push_back(e);
+    return merged;
+  }
+
+
+
+  // For `my_rank`: key -> the OTHER ranks sharing it and the set of regular referencers (n_ranks <= 64)
+  inline std::map<uint64_t, SharedInfo>
+  shared_keys(const Tria &tria, const std::vector<uint16_t> &owner, int n_ranks, int my_rank, int p)
+  {
+    if (n_ranks > 64)
+      throw std::runtime_error("at most 64 ranks are supported");
+    std::map<uint64_t, SharedInfo> out;
+    const auto                   mine = interface_candidate_keys(tria, owner, my_rank, p);
+    for (int q = 0; q < n_ranks; ++q)
+      {
+        if (q == my_rank)
+          continue;
+        const auto theirs = interface_candidate_keys(tria, owner, q, p);
+        size_t     a = 0, b = 0;
+        while (a < mine.size() && b < theirs.size())
+          {
+            if (mine[a].first < theirs[b].first)
+              ++a;
+            else if (theirs[b].first < mine[a].first)
+              ++b;
+            else
+              {
+                SharedInfo &si = out[mine[a].first];
+                si.others |= 1ull << q;
+                if (theirs[b].second & 0x80)
+                  si.regular |= 1ull << q;
+                if (mine[a].second & 0x80)
+                  si.regular |= 1ull << my_rank;
+                ++a;
+                ++b;
+              }
+          }
+      }
+    for (const auto &kv : out)
+      if (!kv.second.regular)
+        throw std::runtime_error("partition: shared DoF without a regular referencer");
+    return out;
+  }
+
+
+
+  // Halo plan of one rank for one level: which tail entries are exchanged with which peer, and how the received
+  // partial sums are combined (ascending rank order, own contribution included at its position).
+  struct HaloPlan
+  {
+    int                   n_ranks = 1, my_rank = 0;
+    std::vector<int>      peers;        // ascending
+    std::vector<uint32_t> peer_offset;  // [peers+1] into pack_idx / the concatenated send and recv buffers
+    std::vector<uint32_t> pack_idx;     // tail index (global index - n_interior) of every send entry
+    std::vector<uint32_t> sh_tail;      // per shared tail DoF: tail index
+    std::vector<uint32_t> sh_ptr;       // CSR over contributions
+    std::vector<int32_t>  sh_src;       // -1 = own value, else position in the concatenated recv buffer; ascending rank
+    std::vector<int32_t>  sh_owner_src; // per shared tail DoF: -1 if this rank owns it, else recv position of the owner's value
+  };
+
+  inline HaloPlan
+  make_halo_plan(const LevelTables &L, const std::map<uint64_t, SharedInfo> &shared, int n_ranks, int my_rank)
+  {
+    HaloPlan H;
+    H.n_ranks = n_ranks;
+    H.my_rank = my_rank;
+    // tail DoFs of this rank that are shared, by key (std::map iterates in ascending key order = canonical order)
+    std::vector<std::vector<std::pair<uint64_t, uint32_t>>> per_peer(n_ranks);
+    std::map<uint32_t, int>                                 owner_of; // tail index -> owning rank
+    for (const auto &kv : shared)
+      {
+        const int32_t *idx = L.keymap.find(kv.first);
+        if (!idx)
+          continue; // candidate key of an interior brick node cannot happen: candidates lie on cell closures of boundary cells
+        const uint32_t gi = (uint32_t)*idx;
+        if (gi < L.n_interior || gi >= L.n_interior + L.n_tail)
+          continue; // Dirichlet / hanging copies carry no partial sums
+        const uint32_t t = gi - L.n_interior;
+        for (int q = 0; q < n_ranks; ++q)
+          if ((kv.second.others >> q) & 1)
+            per_peer[q].push_back({kv.first, t});
+        owner_of[t] = shared_owner(kv.second);
+      }
+    H.peer_offset.push_back(0);
+    std::map<uint32_t, std::vector<std::pair<int, int32_t>>> contrib; // tail index -> (rank, recv position)
+    for (int q = 0; q < n_ranks; ++q)
+      {
+        if (per_peer[q].empty())
+          continue;
+        H.peers.push_back(q);
+        for (const auto &e : per_peer[q])
+          {
+            contrib[e.second].push_back({q, (int32_t)H.pack_idx.size()});
+            H.pack_idx.push_back(e.second);
+          }
+        H.peer_offset.push_back((uint32_t)H.pack_idx.size());
+      }
+    H.sh_ptr.push_back(0);
+    for (auto &kv : contrib)
+      {
+        auto &v = kv.second;
+        v.push_back({my_rank, -1});
+        std::sort(v.begin(), v.end());
+        H.sh_tail.push_back(kv.first);
+        int32_t osrc = -1;
+        for (const auto &e : v)
+          {
+            H.sh_src.push_back(e.second);
+            if (e.first == owner_of[kv.first])
+              osrc = e.second;
+          }
+        H.sh_owner_src.push_back(owner_of[kv.first] == my_rank ? -1 : osrc);
+        if (owner_of[kv.first] != my_rank && osrc < 0)
+          throw std::runtime_error("halo plan: owner of a shared DoF is not a peer");
+        H.sh_ptr.push_back((uint32_t)H.sh_src.size());
+      }
+    return H;
+  }
+} // namespace mgamd

@@ -176,7 +176,10 @@ namespace mgamd
       {
         std::vector<float> f(h.begin(), h.end());
         HIP_CHECK(hipMemcpyAsync(b.data, f.data(), f.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        ctx->sync();
       }
+    ctx->sync();
+    exchange_add_tail(b); // contributions of the other ranks' cells to shared DoFs
     ctx->sync();
   }
 
@@ -285,13 +288,35 @@ namespace mgamd
     DBuf<unsigned long long>                  stamps;     // debug: MGAMD_STAMPS=<mode>, 8 stamps per workgroup of the largest group
     int                                       stamp_mode = -1;
 
-    LevelOperator(Ctx *c, const mgamd_dofs *dofs)
+    // sharded runs: device image of the halo plan
+    struct HaloDev
+    {
+      DBuf<uint32_t> pack_idx, sh_tail, sh_ptr;
+      DBuf<int32_t>  sh_src, sh_owner_src;
+      DBuf<T>        send, recv;
+    };
+    std::unique_ptr<HaloDev> halo;
+
+    LevelOperator(Ctx *c, const mgamd_dofs *dofs, std::shared_ptr<Comm> cm)
     {
       ctx    = c;
       type   = (int)sizeof(T);
       tables = dofs->tables;
       tria   = dofs->tria;
       p      = tables->p;
+      if (cm && dofs->halo)
+        {
+          comm      = cm;
+          halo_plan = dofs->halo;
+          halo      = std::make_unique<HaloDev>();
+          halo->pack_idx.upload(halo_plan->pack_idx);
+          halo->sh_tail.upload(halo_plan->sh_tail);
+          halo->sh_ptr.upload(halo_plan->sh_ptr);
+          halo->sh_src.upload(halo_plan->sh_src);
+          halo->sh_owner_src.upload(halo_plan->sh_owner_src);
+          halo->send.alloc(std::max<size_t>(halo_plan->pack_idx.size(), 1));
+          halo->recv.alloc(std::max<size_t>(halo_plan->pack_idx.size(), 1));
+        }
       if (p > 4)
         throw std::runtime_error("degrees above 4 are not instantiated in this build");
       size_t best = 0;
@@ -331,6 +356,63 @@ namespace mgamd
         }
       tail_acc.alloc(std::max<uint32_t>(tables->n_tail, 1));
       tail_acc.zero(ctx->stream);
+    }
+
+    // tail[t] <- sum over the sharing ranks (ascending rank order) of their partial tail[t]
+    void
+    exchange_add_raw(T *tail)
+    {
+      if (!halo)
+        return;
+      const uint32_t ns = (uint32_t)halo_plan->pack_idx.size();
+      if (ns)
+        hipLaunchKernelGGL(halo_pack_kernel<T>, grid_for(ns), 256, 0, ctx->stream, halo->send.p, tail, halo->pack_idx.p, ns);
+      comm->exchange(halo->send.p, halo->recv.p, halo_plan->peers, halo_plan->peer_offset, sizeof(T), ctx->stream);
+      const uint32_t nsh = (uint32_t)halo_plan->sh_tail.size();
+      if (nsh)
+        hipLaunchKernelGGL(halo_combine_kernel<T>, grid_for(nsh), 256, 0, ctx->stream, tail, halo->recv.p, halo->sh_tail.p, halo->sh_ptr.p,
+                           halo->sh_src.p, nsh);
+      HIP_CHECK(hipGetLastError());
+    }
+    // tail[t] <- the owner's value, for the copies this rank holds of DoFs owned elsewhere
+    void
+    import_from_owner_raw(T *tail)
+    {
+      if (!halo)
+        return;
+      const uint32_t ns = (uint32_t)halo_plan->pack_idx.size();
+      if (ns)
+        hipLaunchKernelGGL(halo_pack_kernel<T>, grid_for(ns), 256, 0, ctx->stream, halo->send.p, tail, halo->pack_idx.p, ns);
+      comm->exchange(halo->send.p, halo->recv.p, halo_plan->peers, halo_plan->peer_offset, sizeof(T), ctx->stream);
+      const uint32_t nsh = (uint32_t)halo_plan->sh_tail.size();
+      if (nsh)
+        hipLaunchKernelGGL(halo_import_kernel<T>, grid_for(nsh), 256, 0, ctx->stream, tail, halo->recv.p, halo->sh_tail.p,
+                           halo->sh_owner_src.p, nsh);
+      HIP_CHECK(hipGetLastError());
+    }
+    void
+    exchange_add_tail(mgamd_vec &v) override
+    {
+      if (v.n != n_dofs())
+        throw std::invalid_argument("exchange_add_tail: vector size mismatch");
+      exchange_add_raw(v.as<T>() + tables->n_interior);
+    }
+    double
+    dot_raw_global(const T *x, const T *y)
+    {
+      if (!comm)
+        return dot_raw(ctx, x, y, (size_t)n_dofs());
+      // constrained entries are zero in every vector of the sharded solver path (homogeneous data), so the owned
+      // prefix [interior | owned tail] counts every DoF exactly once
+      const double local = dot_raw(ctx, x, y, (size_t)tables->n_interior + tables->n_tail_owned);
+      return comm->allreduce_sum_host(local, ctx->stream);
+    }
+    double
+    dot(const mgamd_vec &x, const mgamd_vec &y) override
+    {
+      if (x.n != n_dofs() || y.n != n_dofs())
+        throw std::invalid_argument("dot: vector size mismatch");
+      return dot_raw_global(x.as<T>(), y.as<T>());
     }
 
     template <int P>
@@ -388,6 +470,8 @@ namespace mgamd
               ctx->prof_bytes += words * sizeof(T) * (double)g->n_slots * n1 * n1 * n1;
             }
         }
+      if (halo)
+        exchange_add_raw(tail_acc.p); // complete the shared tail sums across ranks before the epilogue
       const uint32_t n_rest = tables->n_dofs - tables->n_interior - tables->n_tail;
       const uint32_t n_t    = tables->n_tail + n_rest;
       if (n_t)
@@ -477,12 +561,12 @@ namespace mgamd
   };
 
   LevelOperatorBase *
-  make_level_operator(Ctx *ctx, const mgamd_dofs *dofs, int type)
+  make_level_operator(Ctx *ctx, const mgamd_dofs *dofs, int type, std::shared_ptr<Comm> comm)
   {
     if (type == MGAMD_F64)
-      return new LevelOperator<double>(ctx, dofs);
+      return new LevelOperator<double>(ctx, dofs, comm);
     if (type == MGAMD_F32)
-      return new LevelOperator<float>(ctx, dofs);
+      return new LevelOperator<float>(ctx, dofs, comm);
     throw std::invalid_argument("number_type must be MGAMD_F64 or MGAMD_F32");
   }
 
@@ -601,12 +685,37 @@ namespace mgamd
       const size_t n   = lop->n_dofs();
       // initial guess (deal.II set_initial_guess): v_i = (i mod 11) - mean
       std::vector<T> v(n);
-      double         sum = 0;
-      for (size_t i = 0; i < n; ++i)
-        sum += (double)(i % 11);
-      const T mean = (T)(sum / (double)n);
-      for (size_t i = 0; i < n; ++i)
-        v[i] = (T)(i % 11) - mean;
+      const char    *key_init = getenv("MGAMD_CHEB_KEY_INIT"); // tests: numbering-independent start vector on one rank too
+      if (!lop->comm && !(key_init && atoi(key_init)))
+        {
+          double sum = 0;
+          for (size_t i = 0; i < n; ++i)
+            sum += (double)(i % 11);
+          const T mean = (T)(sum / (double)n);
+          for (size_t i = 0; i < n; ++i)
+            v[i] = (T)(i % 11) - mean;
+        }
+      else
+        {
+          // sharded: there is no global index; use a numbering-independent value per DoF (a hash of its geometric
+          // key, identical on every sharing rank), zero on constrained DoFs so that every entry is counted once
+          std::vector<DofKey> keys;
+          lop->tables->export_dof_keys(keys);
+          const size_t nf = (size_t)lop->tables->n_interior + lop->tables->n_tail, nown = (size_t)lop->tables->n_interior + lop->tables->n_tail_owned;
+          double       sum = 0;
+          for (size_t i = 0; i < n; ++i)
+            {
+              const uint64_t hk = FlatMap::mix(pack_key((uint32_t)keys[i].px, (uint32_t)keys[i].py, (uint32_t)keys[i].pz, keys[i].dirmask, keys[i].level));
+              v[i]              = i < nf ? (T)(hk % 11) : T(0);
+              if (i < nown)
+                sum += (double)v[i];
+            }
+          const double gsum = lop->comm ? lop->comm->allreduce_sum_host(sum, ctx->stream) : sum;
+          const double gcnt = lop->comm ? lop->comm->allreduce_sum_host((double)nown, ctx->stream) : (double)nown;
+          const T      mean = (T)(gsum / gcnt);
+          for (size_t i = 0; i < nf; ++i)
+            v[i] -= mean;
+        }
       DBuf<T> r, z, d, Ad;
       r.upload(v);
       z.alloc(n);
@@ -614,6 +723,7 @@ namespace mgamd
       Ad.alloc(n);
       std::vector<double> alphas, betas;
       const int           g    = grid_for(n);
+      auto                dot_raw = [&](Ctx *, const T *a, const T *b, size_t) { return lop->dot_raw_global(a, b); };
       double              res0 = std::sqrt(dot_raw(ctx, r.p, r.p, n));
       if (res0 > 0 && n_it > 0)
         {
@@ -740,7 +850,7 @@ namespace mgamd
     {
       int                 kind = 0, nf = 2;
       size_t              n_patches = 0;
-      DBuf<uint32_t>      coarse_idx, fine_idx;
+      DBuf<uint32_t>      coarse_idx, fine_idx, fine_idx_restrict; // restrict list: copies of other ranks' DoFs removed
       DBuf<uint16_t>      coarse_mask;
       std::vector<double> E;
     };
@@ -748,11 +858,11 @@ namespace mgamd
     {
       int            B = 2, fine_group = 0;
       size_t         n_bricks = 0;
-      DBuf<uint32_t> slot, coarse_idx, own_shell;
+      DBuf<uint32_t> slot, coarse_idx, own_shell, own_shell_restrict;
     };
     GroupD                               grp[3];
     std::vector<std::unique_ptr<BrickD>> bricks;
-    LevelOperator<T>                    *fop = nullptr;
+    LevelOperator<T>                    *fop = nullptr, *cop = nullptr;
     int                                  pc = 1, pf = 1;
     Ctx                                 *ctx = nullptr;
     FE1D                                 fec;
@@ -763,9 +873,18 @@ namespace mgamd
       fine   = f;
       coarse = c;
       fop    = f;
+      cop    = c;
       ctx    = f->ctx;
       const char    *nb = getenv("MGAMD_NO_BRICK_TRANSFER");
       TransferTables tt(*f->tables, *c->tables, !(nb && atoi(nb)));
+      // sharded fine level: a residual entry that is a copy of another rank's DoF is restricted by its owner only
+      const uint32_t copy_lo = f->tables->n_interior + f->tables->n_tail_owned, copy_hi = f->tables->n_interior + f->tables->n_tail;
+      auto           owned_only = [&](std::vector<uint32_t> v) {
+        for (uint32_t &i : v)
+          if (i != INVALID_DOF && i >= copy_lo && i < copy_hi)
+            i = INVALID_DOF;
+        return v;
+      };
       for (const BrickTransferGroup &bg : tt.bricks)
         {
           auto d        = std::make_unique<BrickD>();
@@ -775,6 +894,8 @@ namespace mgamd
           d->slot.upload(bg.slot);
           d->coarse_idx.upload(bg.coarse_idx);
           d->own_shell.upload(bg.own_shell);
+          if (copy_hi > copy_lo)
+            d->own_shell_restrict.upload(owned_only(bg.own_shell));
           bricks.push_back(std::move(d));
         }
       pc = tt.pc;
@@ -789,6 +910,8 @@ namespace mgamd
               grp[k].coarse_idx.upload(tt.groups[k].coarse_idx);
               grp[k].coarse_mask.upload(tt.groups[k].coarse_mask);
               grp[k].fine_idx.upload(tt.groups[k].fine_idx);
+              if (copy_hi > copy_lo)
+                grp[k].fine_idx_restrict.upload(owned_only(tt.groups[k].fine_idx));
             }
           grp[k].E = fec.embedding(k, pf);
         }
@@ -802,7 +925,7 @@ namespace mgamd
       TransferArgs<T, PC, NF> a;
       a.coarse_idx  = g.coarse_idx.p;
       a.coarse_mask = g.coarse_mask.p;
-      a.fine_idx    = g.fine_idx.p;
+      a.fine_idx    = (!prolongate && g.fine_idx_restrict.p) ? g.fine_idx_restrict.p : g.fine_idx.p;
       a.n_patches   = (uint32_t)g.n_patches;
       const int n   = PC + 1;
       for (int i = 0; i < n * n; ++i)
@@ -837,7 +960,7 @@ namespace mgamd
       a.interior_base = fg.interior_base.p;
       a.shell_pos     = fg.shell_pos.p;
       a.coarse_idx    = b.coarse_idx.p;
-      a.own_shell     = b.own_shell.p;
+      a.own_shell     = (!prolongate && b.own_shell_restrict.p) ? b.own_shell_restrict.p : b.own_shell.p;
       a.n_bricks      = (uint32_t)b.n_bricks;
       const std::vector<double> E = fec.embedding(1, P);
       for (int i = 0; i < (2 * P + 1) * (P + 1); ++i)
@@ -969,11 +1092,20 @@ namespace mgamd
     prolongate_raw(T *dst_fine, const T *src_coarse)
     {
       run(src_coarse, dst_fine, true);
+      // sharded runs: a rank that references a shared DoF only through hanging-node resolution has no patch writing its
+      // copy, and different ranks evaluate the embedding through different patches: all copies take the owner's value
+      if (fop->halo)
+        fop->import_from_owner_raw(dst_fine + fop->tables->n_interior);
     }
     void
     restrict_raw(T *dst_coarse, const T *src_fine)
     {
       run(src_fine, dst_coarse, false);
+      // sharded runs: complete the coarse defect across ranks
+      if (cop->halo)
+        cop->exchange_add_raw(dst_coarse + cop->tables->n_interior);
+      else if (fop->comm)
+        fop->comm->allreduce_sum(dst_coarse, cop->n_dofs(), (int)sizeof(T), ctx->stream); // onto the replicated level
     }
     void
     prolongate_and_add(mgamd_vec &dst, const mgamd_vec &src) override
@@ -1316,7 +1448,7 @@ namespace mgamd
         return 0.0;
       if (cb)
         throw std::invalid_argument("time_vcycles: remove the stage callback first");
-      const bool graphable = coarse_type == "direct";
+      const bool graphable = coarse_type == "direct" && !ops[nl - 1]->comm;
       vcycle(z, r); // warm-up: sets kernel attributes, touches memory
       ctx->sync();
       if (use_graph && graphable && (!graph_exec || graph_z != z.data || graph_r != r.data))
@@ -1396,7 +1528,7 @@ namespace mgamd
       Ad(vec_create(ctx, n, A.type));
     vec_set(x, 0.0); // dst = 0 (ref:multigrid_throughput.cc:1142,1245)
     vec_copy(*g, b); // residual r = b - A*0
-    double res   = std::sqrt(vec_dot(*g, *g));
+    double res   = std::sqrt(A.dot(*g, *g));
     const double res0 = res;
     n_iterations = 0;
     residual     = res;
@@ -1410,20 +1542,20 @@ namespace mgamd
     };
     precond();
     vec_copy(*d, *h);
-    double gh = vec_dot(*g, *h);
+    double gh = A.dot(*g, *h);
     for (unsigned it = 1; it <= maxiter; ++it)
       {
         A.vmult(*Ad, *d);
-        const double alpha = gh / vec_dot(*d, *Ad);
+        const double alpha = gh / A.dot(*d, *Ad);
         vec_sadd(x, 1.0, alpha, *d);
         vec_sadd(*g, 1.0, -alpha, *Ad);
-        res          = std::sqrt(vec_dot(*g, *g));
+        res          = std::sqrt(A.dot(*g, *g));
         n_iterations = it;
         residual     = res;
         if (res < reltol * res0 || res <= abstol)
           break;
         precond();
-        const double gh_new = vec_dot(*g, *h);
+        const double gh_new = A.dot(*g, *h);
         const double beta   = gh_new / gh;
         gh                  = gh_new;
         vec_sadd(*d, beta, 1.0, *h);

@@ -5,6 +5,7 @@
 // Multigrid <-> Multigrid + PreconditionMG + MGTransferGlobalCoarsening, solve_cg <-> SolverCG.
 #pragma once
 #include "api_common.hpp"
+#include "comm.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -150,7 +151,20 @@ namespace mgamd
     int                          type = MGAMD_F64;
     std::shared_ptr<LevelTables> tables;
     std::shared_ptr<Tria>        tria;
+    std::shared_ptr<Comm>        comm; // sharded runs: set when this level is distributed
+    std::shared_ptr<HaloPlan>    halo_plan;
     virtual ~LevelOperatorBase() = default;
+    // inner product counting every DoF once across ranks (copies of DoFs owned by other ranks are skipped)
+    virtual double
+    dot(const mgamd_vec &x, const mgamd_vec &y) = 0;
+    // sum over the sharing ranks of the tail entries of a vector (in place); no-op on one rank
+    virtual void
+    exchange_add_tail(mgamd_vec &v) = 0;
+    uint64_t
+    n_dofs_owned() const
+    {
+      return (uint64_t)tables->n_interior + tables->n_tail_owned + tables->n_dirichlet_owned + tables->n_hanging_owned;
+    }
     uint32_t
     n_dofs() const
     {
@@ -201,7 +215,7 @@ namespace mgamd
   };
 
   LevelOperatorBase *
-  make_level_operator(Ctx *ctx, const mgamd_dofs *dofs, int type);
+  make_level_operator(Ctx *ctx, const mgamd_dofs *dofs, int type, std::shared_ptr<Comm> comm = nullptr);
   ChebyshevBase *
   make_chebyshev(LevelOperatorBase *op, unsigned degree, double smoothing_range, unsigned eig_cg_n_iterations);
   Transfer2Base *

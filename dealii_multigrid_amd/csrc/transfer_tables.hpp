@@ -93,7 +93,7 @@ namespace mgamd
                     for (int cx = 0; ok && cx < Bc; ++cx)
                       {
                         const int32_t *par = tc.index.find(cell_key(anchor.level - 1, (anchor.i >> 1) + cx, (anchor.j >> 1) + cy, (anchor.k >> 1) + cz));
-                        if (!par || (tc.masks[*par] >> MASK_FACE_SHIFT))
+                        if (!par || (tc.masks[*par] >> MASK_FACE_SHIFT) || !coarse.cell_is_local((size_t)*par))
                           ok = false;
                         else
                           parents[(cz * Bc + cy) * Bc + cx] = *par;
@@ -132,18 +132,32 @@ namespace mgamd
           }
       for (size_t ci = 0; ci < tc.cells.size(); ++ci)
         {
-          if (covered[ci])
+          if (covered[ci] || !coarse.cell_is_local(ci))
             continue;
           const Cell    &cc = tc.cells[ci];
           const int32_t *same = tf.index.find(cell_key(cc));
           int            kind;
           if (same)
-            kind = pf == pc ? 0 : 2;
+            {
+              kind = pf == pc ? 0 : 2;
+              if (!fine.cell_is_local((size_t)*same))
+                continue; // distributed fine level over a replicated coarse level: another rank's patch
+            }
           else
             {
               if (pf != pc)
                 throw std::runtime_error("transfer: refined cell in a p-transfer");
               kind = 1;
+              // at the partition's root level the 8 children may belong to different ranks: keep the patch if any is ours
+              bool any_local = false;
+              for (int t = 0; t < 8; ++t)
+                {
+                  const int32_t *f = tf.index.find(cell_key(cc.level + 1, 2 * cc.i + (t & 1), 2 * cc.j + ((t >> 1) & 1), 2 * cc.k + (t >> 2)));
+                  if (f && fine.cell_is_local((size_t)*f))
+                    any_local = true;
+                }
+              if (!any_local)
+                continue;
             }
           TransferGroup &g = groups[kind];
           g.coarse_mask.push_back(tc.masks[ci]);
@@ -159,24 +173,38 @@ namespace mgamd
             for (int Y = 0; Y < nf; ++Y)
               for (int X = 0; X < nf; ++X)
                 {
-                  size_t fci;
-                  int    l[3] = {X, Y, Z};
+                  uint32_t idx = INVALID_DOF;
                   if (kind == 1)
                     {
-                      const int      ch[3] = {X > pc ? 1 : 0, Y > pc ? 1 : 0, Z > pc ? 1 : 0};
-                      const int32_t *f     = tf.index.find(cell_key(cc.level + 1, 2 * cc.i + ch[0], 2 * cc.j + ch[1], 2 * cc.k + ch[2]));
-                      if (!f)
-                        throw std::runtime_error("transfer: fine mesh is not a one-level refinement of the coarse mesh");
-                      fci = (size_t)*f;
-                      for (int d = 0; d < 3; ++d)
-                        l[d] -= ch[d] * pc;
+                      // a node on the plane between two children belongs to both: take the first LOCAL child for which
+                      // it is a regular (non-hanging) node
+                      const int lo[3] = {X > pc ? 1 : 0, Y > pc ? 1 : 0, Z > pc ? 1 : 0};
+                      const int hi[3] = {X >= pc ? 1 : 0, Y >= pc ? 1 : 0, Z >= pc ? 1 : 0};
+                      for (int cz = lo[2]; cz <= hi[2] && idx == INVALID_DOF; ++cz)
+                        for (int cy = lo[1]; cy <= hi[1] && idx == INVALID_DOF; ++cy)
+                          for (int cx = lo[0]; cx <= hi[0] && idx == INVALID_DOF; ++cx)
+                            {
+                              const int32_t *f = tf.index.find(cell_key(cc.level + 1, 2 * cc.i + cx, 2 * cc.j + cy, 2 * cc.k + cz));
+                              if (!f)
+                                throw std::runtime_error("transfer: fine mesh is not a one-level refinement of the coarse mesh");
+                              if (!fine.cell_is_local((size_t)*f))
+                                continue;
+                              const int l[3] = {X - cx * pc, Y - cy * pc, Z - cz * pc};
+                              bool      constrained, corner;
+                              uint32_t  v = fine.cell_node_index((size_t)*f, l, &constrained, &corner);
+                              if (constrained && !corner)
+                                v = INVALID_DOF; // own DoF is a hanging node: weight 0
+                              idx = v;
+                            }
                     }
                   else
-                    fci = (size_t)*same;
-                  bool     constrained, corner;
-                  uint32_t idx = fine.cell_node_index(fci, l, &constrained, &corner);
-                  if (constrained && !corner)
-                    idx = INVALID_DOF; // own DoF is a hanging node: weight 0
+                    {
+                      const int l[3] = {X, Y, Z};
+                      bool      constrained, corner;
+                      idx = fine.cell_node_index((size_t)*same, l, &constrained, &corner);
+                      if (constrained && !corner)
+                        idx = INVALID_DOF;
+                    }
                   if (idx != INVALID_DOF)
                     {
                       if (claimed[idx])

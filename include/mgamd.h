@@ -40,6 +40,9 @@ typedef struct mgamd_level_op  mgamd_level_op;  /* Operator<3,1,Number>  (ref:in
 typedef struct mgamd_cheb      mgamd_cheb;      /* PreconditionChebyshev<Operator,Vector,DiagonalMatrix> */
 typedef struct mgamd_transfer2 mgamd_transfer2; /* MGTwoLevelTransfer<3,Vector>                          */
 typedef struct mgamd_mg        mgamd_mg;        /* Multigrid + PreconditionMG + MGTransferGlobalCoarsening */
+typedef struct mgamd_partition mgamd_partition; /* domain decomposition of the level hierarchy (one rank per GPU) */
+typedef struct mgamd_comm      mgamd_comm;      /* communicator: RCCL over xGMI, or the in-process simulator      */
+typedef struct mgamd_sim_group mgamd_sim_group; /* the ranks of one in-process simulation                         */
 
 const char *mgamd_last_error(void);
 const char *mgamd_version(void);
@@ -74,6 +77,10 @@ typedef struct
   uint32_t n_groups;    /* slot groups (brick sizes)                                         */
   uint32_t group_B[8];  /* cells per direction of each group's bricks                        */
   uint64_t group_slots[8];
+  /* sharded levels (mgamd_dofs_create_local): the tail is [owned | copies]; *_owned count each DoF once globally */
+  uint32_t n_tail_owned, n_dirichlet_owned, n_hanging_owned;
+  uint32_t n_peers;       /* ranks this rank exchanges partial sums with on this level               */
+  uint32_t n_halo_send;   /* tail entries sent (= received) per exchange                              */
 } mgamd_dofs_info_t;
 
 /* DoFHandler::distribute_dofs(FE_Q(degree)) + zero Dirichlet on boundary id 0 + hanging-node
@@ -91,6 +98,20 @@ int mgamd_dofs_get_cell_dofs(const mgamd_dofs *d, uint32_t *out);
 /* Operator::rhs for f == 1, g == 0 (ref:include/operator.h:362-447, ref:multigrid_throughput.cc:2286-2291) */
 int mgamd_dofs_rhs_constant(const mgamd_dofs *d, double *out);
 
+/* Domain decomposition (the reference partitions with p4est + RepartitioningPolicyTools,
+ * ref:multigrid_throughput.cc:2066-2175).  trias: the level meshes, coarsest first.  A root level is chosen; its leaves are
+ * cut in Morton order into n_ranks chunks of equal weight (hanging-node cells weigh `hanging_weight`, cf. CellWeightPolicy);
+ * finer levels inherit the owner of their root ancestor, coarser levels are replicated on every rank. */
+int mgamd_partition_create(const mgamd_tria *const *trias, unsigned n_levels, unsigned n_ranks, double hanging_weight,
+                           mgamd_partition **out);
+int mgamd_partition_destroy(mgamd_partition *p);
+int mgamd_partition_info(const mgamd_partition *p, unsigned *root_level, unsigned *n_ranks);
+/* owner rank of every cell of a distributed level (level >= root_level) */
+int mgamd_partition_get_owner(const mgamd_partition *p, unsigned level, uint16_t *owner);
+/* level tables of one rank: distributed levels hold the rank's cells only (plus its halo plan), replicated levels are
+ * identical to mgamd_dofs_create */
+int mgamd_dofs_create_local(const mgamd_partition *p, unsigned level, unsigned rank, int degree, int max_brick, mgamd_dofs **out);
+
 /* raw two-level transfer tables (for the CPU oracle): kind 0 identity, 1 h-embedding, 2 p-embedding */
 int mgamd_transfer_tables_info(const mgamd_dofs *fine, const mgamd_dofs *coarse, uint64_t n_patches[3], uint32_t nf[3]);
 int mgamd_transfer_tables_get(const mgamd_dofs *fine, const mgamd_dofs *coarse, int kind, uint32_t *coarse_idx,
@@ -104,6 +125,18 @@ int mgamd_ctx_destroy(mgamd_ctx *ctx);
 int mgamd_ctx_synchronize(mgamd_ctx *ctx);
 /* the HIP stream all work of this context is submitted to (hipStream_t as void*) */
 int mgamd_ctx_stream(mgamd_ctx *ctx, void **stream);
+
+/* Communicators.  RCCL: every rank calls mgamd_comm_rccl_create with the same 128-byte id obtained once from
+ * mgamd_comm_rccl_unique_id (distribute it with any host-side channel, e.g. torch.distributed / MPI).  Simulator: all
+ * ranks live in one process as host threads sharing one GPU; used to test the sharded path on a single device. */
+int mgamd_comm_rccl_unique_id(char id[128]);
+int mgamd_comm_rccl_create(mgamd_ctx *ctx, unsigned n_ranks, unsigned rank, const char id[128], mgamd_comm **out);
+int mgamd_sim_group_create(unsigned n_ranks, mgamd_sim_group **out);
+int mgamd_sim_group_destroy(mgamd_sim_group *g);
+int mgamd_comm_sim_create(mgamd_sim_group *g, unsigned rank, mgamd_comm **out);
+int mgamd_comm_destroy(mgamd_comm *c);
+/* sum of a host scalar over all ranks (blocking) */
+int mgamd_comm_allreduce_sum(mgamd_comm *c, mgamd_ctx *ctx, double value, double *result);
 
 /* number_type: 8 = double, 4 = float (MGNumberType, ref:multigrid_throughput.cc:2430-2433) */
 #define MGAMD_F64 8
@@ -124,7 +157,14 @@ int mgamd_vec_norm2(const mgamd_vec *x, double *result);
 
 /* Operator::reinit (ref:include/operator.h:24-47) */
 int mgamd_level_op_create(mgamd_ctx *ctx, const mgamd_dofs *dofs, int number_type, mgamd_level_op **out);
+/* same, for a level built with mgamd_dofs_create_local: vmult / inverse diagonal / rhs / smoother / transfers complete
+ * the sums of shared DoFs across ranks through `comm` (may be NULL for replicated levels) */
+int mgamd_level_op_create_distributed(mgamd_ctx *ctx, const mgamd_dofs *dofs, int number_type, mgamd_comm *comm, mgamd_level_op **out);
 int mgamd_level_op_destroy(mgamd_level_op *op);
+/* inner product over the GLOBAL vector (every DoF counted once across ranks) */
+int mgamd_level_op_dot(mgamd_level_op *op, const mgamd_vec *x, const mgamd_vec *y, double *result);
+/* number of DoFs this rank owns (sums to DoFHandler::n_dofs() over the ranks) */
+int mgamd_level_op_n_owned(const mgamd_level_op *op, uint64_t *n);
 int mgamd_level_op_m(const mgamd_level_op *op, uint64_t *n); /* Operator::m (ref:include/operator.h:123) */
 /* Operator::initialize_dof_vector (ref:include/operator.h:140) */
 int mgamd_level_op_init_vector(const mgamd_level_op *op, mgamd_vec **out);
