@@ -9,9 +9,10 @@ SmootherDegree 3 -- synthetic data (f == 1, zero Dirichlet), no dataset.  The p 
 north_star also asks for is reported in the same line under "also".
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by torch.distributed.run, one rank per GPU; this round the path is sharded as
-   independent replicas -- every rank runs the full single-GPU workload, no data-path collective,
-   value = N * n_dofs / max-over-ranks time)
+  (N > 1: launched by torch.distributed.run, one rank per GPU.  The SAME global problem is sharded by spatial domain
+   decomposition: every rank owns a Morton chunk of the octree, shared DoFs are exchanged with grouped RCCL
+   send/recv over xGMI, the replicated coarse levels take one RCCL all-reduce -> "scaling": "strong",
+   value = global n_dofs / max-over-ranks time; see DESIGN.md section 7.  `--mode replicas` runs N independent copies.)
 
 Prints ONE JSON line on rank 0.
 """
@@ -33,9 +34,12 @@ def algorithmic_bytes_per_vcycle(n_dofs_per_level, k=3, word=8):
     return word * ((10 * k + 3) * sum(N[1:]) + 2 * sum(N[:-1]))
 
 
-def run_workload(m, ctx, geometry, n_ref, degree, steps, warmup, barrier, sync, profile):
+def run_workload(m, ctx, geometry, n_ref, degree, steps, warmup, barrier, sync, profile, comm=None):
     t0 = time.time()
-    h = m.Hierarchy(ctx, geometry, n_ref, degree, "HMG-global", smoother_degree=3, coarse_solver="amg", number_type=m.F64)
+    if comm is None:
+        h = m.Hierarchy(ctx, geometry, n_ref, degree, "HMG-global", smoother_degree=3, coarse_solver="amg", number_type=m.F64)
+    else:
+        h = m.DistributedHierarchy(ctx, comm, geometry, n_ref, degree, smoother_degree=3, coarse_solver="amg", number_type=m.F64)
     b, z = h.fine_operator.initialize_dof_vector(), h.fine_operator.initialize_dof_vector()
     h.fine_operator.rhs(b)
     ctx.synchronize()
@@ -56,9 +60,16 @@ def run_workload(m, ctx, geometry, n_ref, degree, steps, warmup, barrier, sync, 
     if profile:
         prof = ctx.kernel_profile_read()
         ctx.kernel_profile(False)
-    N = [d.n_dofs for d in h.dofs]
+    if comm is None:
+        N = [d.n_dofs for d in h.dofs]
+    else:  # global level sizes: owned DoFs summed over the ranks (replicated levels are complete on every rank)
+        N = [int(round(comm.allreduce_sum(ctx, float(op.n_owned())))) if l >= h.partition.root_level else h.dofs[l].n_dofs
+             for l, op in enumerate(h.operators)]
     res = dict(n_dofs=h.n_dofs, n_cells=h.trias[-1].n_cells, n_levels=len(N), level_dofs=N, elapsed=elapsed, setup_s=setup_s,
                bytes_per_vcycle=algorithmic_bytes_per_vcycle(N), groups=h.dofs[-1].groups(), prof=prof)
+    if comm is not None:
+        info = h.dofs[-1].info
+        res["halo"] = dict(root_level=h.partition.root_level, peers=info.n_peers, halo_send_entries=info.n_halo_send, n_local=h.n_local)
     # reference protocol for context: CG solve to reltol 1e-4 (ref:multigrid_throughput.cc:1238-1254)
     x = h.fine_operator.initialize_dof_vector()
     t0 = time.perf_counter()
@@ -107,6 +118,7 @@ def main():
     ap.add_argument("--nref", type=int, default=8, help="NRefGlobal of the primary workload (octant p=4)")
     ap.add_argument("--nref-p1", type=int, default=9, help="NRefGlobal of the secondary octant p=1 workload")
     ap.add_argument("--cpu-nref", type=int, default=6, help="NRefGlobal of the CPU-baseline sample")
+    ap.add_argument("--mode", choices=["sharded", "replicas"], default="sharded", help="N > 1: domain decomposition (default) or replicas")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
@@ -133,14 +145,35 @@ def main():
     import dealii_multigrid_amd as m
 
     ctx = m.Context(local_rank)
-    prim = run_workload(m, ctx, "quadrant", args.nref, 4, args.steps, args.warmup, barrier, sync, profile=True)
+    mode, note = ("single", None) if world == 1 else (args.mode, None)
+    prim = None
+    if mode == "sharded":
+        try:
+            uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(m.Communicator.rccl_unique_id()), dtype=torch.uint8))
+            dist.broadcast(uid, 0)
+            comm = m.Communicator.rccl(ctx, world, rank, bytes(uid.cpu().numpy().tobytes()))
+            prim = run_workload(m, ctx, "quadrant", args.nref, 4, args.steps, args.warmup, barrier, sync, profile=True, comm=comm)
+            ok = 1.0
+        except Exception as e:  # noqa: BLE001 -- reported in the JSON line, never silent
+            ok, note = 0.0, f"sharded run failed on rank {rank}: {type(e).__name__}: {e}"
+            print(note, file=sys.stderr, flush=True)
+        flag = torch.tensor([ok], device="cuda", dtype=torch.float64)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if flag.item() < 0.5:
+            mode, prim = "replicas", None
+            note = note or "sharded run failed on another rank"
+    if prim is None:
+        prim = run_workload(m, ctx, "quadrant", args.nref, 4, args.steps, args.warmup, barrier, sync, profile=True)
     elapsed = prim["elapsed"]
     if dist is not None:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
-    value = world * prim["n_dofs"] / (elapsed / args.steps)
+    # sharded: ONE global problem; replicas: N copies of it
+    value = (world if mode == "replicas" else 1) * prim["n_dofs"] / (elapsed / args.steps)
 
     out = {
         "metric": "DoF/s per V-cycle, 3D octant p=4",
@@ -151,7 +184,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "weak" if mode == "replicas" else "strong",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
@@ -159,13 +192,19 @@ def main():
             "workload": f"3D octant (GeometryType quadrant) HMG-global p=4 FP64, NRefGlobal={args.nref}, SmootherDegree=3, "
                         f"coarse solver direct, f=1, zero Dirichlet (BASELINE.json configs[2])",
             "n_dofs": prim["n_dofs"], "n_cells": prim["n_cells"], "n_levels": prim["n_levels"],
-            "parallelism": "1 GPU" if world == 1 else f"replicas x{world} (no data-path collective this round)",
+            "parallelism": "1 GPU" if world == 1 else (
+                f"domain decomposition over {world} GPUs: RCCL send/recv halo exchange + all-reduce onto replicated coarse levels"
+                if mode == "sharded" else f"replicas x{world} (no data-path collective)"),
             "cg_iterations_reltol_1e-4": prim["cg_iterations"],
         },
     }
-    # whole-V-cycle roofline figure and the dominant kernel's
-    vcycle_gbs = prim["bytes_per_vcycle"] / (elapsed / args.steps) / 1e9
-    out["vcycle_algorithmic_GBps"] = vcycle_gbs
+    if note:
+        out["config"]["note"] = note
+    if "halo" in prim:
+        out["config"]["halo_rank0"] = prim["halo"]
+    # whole-V-cycle roofline figure (against the aggregate HBM bandwidth of the GPUs used) and the dominant kernel's
+    vcycle_gbs = (world if mode == "replicas" else 1) * prim["bytes_per_vcycle"] / (elapsed / args.steps) / 1e9 / world
+    out["vcycle_algorithmic_GBps_per_gpu"] = vcycle_gbs
     out["vcycle_frac_of_hbm_peak"] = vcycle_gbs / HBM_PEAK_GBS
     if prim["prof"] and prim["prof"][1] > 0:
         ms, n, by = prim["prof"]

@@ -180,6 +180,19 @@ class DoFs:
     def groups(self):
         return [(self.info.group_B[g], self.info.group_slots[g]) for g in range(self.info.n_groups)]
 
+    def halo_plan(self):
+        """host copy of the halo plan of a distributed level (see mgamd_dofs_halo_get)."""
+        sz = (C.c_uint32 * 4)()
+        _chk(_lib.mgamd_dofs_halo_sizes(self._h, sz))
+        npeer, nsend, nsh, nc = (int(v) for v in sz)
+        plan = dict(peers=np.zeros(npeer, np.int32), peer_offset=np.zeros(npeer + 1, np.uint32), pack_idx=np.zeros(nsend, np.uint32),
+                    sh_tail=np.zeros(nsh, np.uint32), sh_ptr=np.zeros(nsh + 1, np.uint32), sh_src=np.zeros(nc, np.int32),
+                    sh_owner_src=np.zeros(nsh, np.int32))
+        if npeer:
+            _chk(_lib.mgamd_dofs_halo_get(self._h, _ptr(plan["peers"]), _ptr(plan["peer_offset"]), _ptr(plan["pack_idx"]), _ptr(plan["sh_tail"]),
+                                          _ptr(plan["sh_ptr"]), _ptr(plan["sh_src"]), _ptr(plan["sh_owner_src"])))
+        return plan
+
     def __del__(self):
         if getattr(self, "_h", None):
             _lib.mgamd_dofs_destroy(self._h)

@@ -275,6 +275,45 @@ mgamd_dofs_create_local(const mgamd_partition *p, unsigned level, unsigned rank,
 }
 
 int
+mgamd_dofs_halo_sizes(const mgamd_dofs *d, uint32_t sizes[4])
+{
+  MGAMD_TRY
+  if (!d || !sizes)
+    throw std::invalid_argument("null argument");
+  sizes[0] = sizes[1] = sizes[2] = sizes[3] = 0;
+  if (d->halo)
+    {
+      sizes[0] = (uint32_t)d->halo->peers.size();
+      sizes[1] = (uint32_t)d->halo->pack_idx.size();
+      sizes[2] = (uint32_t)d->halo->sh_tail.size();
+      sizes[3] = (uint32_t)d->halo->sh_src.size();
+    }
+  MGAMD_CATCH
+}
+
+int
+mgamd_dofs_halo_get(const mgamd_dofs *d, int32_t *peers, uint32_t *peer_offset, uint32_t *pack_idx, uint32_t *sh_tail, uint32_t *sh_ptr,
+                    int32_t *sh_src, int32_t *sh_owner_src)
+{
+  MGAMD_TRY
+  if (!d || !d->halo)
+    throw std::invalid_argument("not a distributed level");
+  const HaloPlan &H   = *d->halo;
+  auto            cpy = [](auto *dst, const auto &v) {
+    if (dst && !v.empty())
+      std::memcpy(dst, v.data(), v.size() * sizeof(v[0]));
+  };
+  cpy(peers, H.peers);
+  cpy(peer_offset, H.peer_offset);
+  cpy(pack_idx, H.pack_idx);
+  cpy(sh_tail, H.sh_tail);
+  cpy(sh_ptr, H.sh_ptr);
+  cpy(sh_src, H.sh_src);
+  cpy(sh_owner_src, H.sh_owner_src);
+  MGAMD_CATCH
+}
+
+int
 mgamd_transfer_tables_info(const mgamd_dofs *fine, const mgamd_dofs *coarse, uint64_t n_patches[3], uint32_t nf[3])
 {
   MGAMD_TRY

@@ -112,6 +112,14 @@ int mgamd_partition_get_owner(const mgamd_partition *p, unsigned level, uint16_t
  * identical to mgamd_dofs_create */
 int mgamd_dofs_create_local(const mgamd_partition *p, unsigned level, unsigned rank, int degree, int max_brick, mgamd_dofs **out);
 
+/* halo plan of a distributed level (tests / host-side emulation): sizes = {n_peers, n_send, n_shared, n_contrib};
+ * peers[n_peers], peer_offset[n_peers+1], pack_idx[n_send] (tail index = global index - n_interior), and for every shared
+ * tail DoF its tail index sh_tail[n_shared], CSR sh_ptr[n_shared+1] into sh_src[n_contrib] (-1 = own partial, else position
+ * in the concatenated receive buffer, ascending rank order) and sh_owner_src[n_shared] (-1 if this rank owns the DoF) */
+int mgamd_dofs_halo_sizes(const mgamd_dofs *d, uint32_t sizes[4]);
+int mgamd_dofs_halo_get(const mgamd_dofs *d, int32_t *peers, uint32_t *peer_offset, uint32_t *pack_idx, uint32_t *sh_tail,
+                        uint32_t *sh_ptr, int32_t *sh_src, int32_t *sh_owner_src);
+
 /* raw two-level transfer tables (for the CPU oracle): kind 0 identity, 1 h-embedding, 2 p-embedding */
 int mgamd_transfer_tables_info(const mgamd_dofs *fine, const mgamd_dofs *coarse, uint64_t n_patches[3], uint32_t nf[3]);
 int mgamd_transfer_tables_get(const mgamd_dofs *fine, const mgamd_dofs *coarse, int kind, uint32_t *coarse_idx,
