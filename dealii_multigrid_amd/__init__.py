@@ -490,6 +490,13 @@ class Hierarchy:
         elif mg_type == "PMG":
             self.degrees = create_polynomial_coarsening_sequence(degree)
             self.trias = [fine] * len(self.degrees)
+        elif mg_type == "HPMG":
+            # h-levels at the lowest degree of the bisection sequence, then the p-levels on the finest mesh
+            # (ref:multigrid_throughput.cc:1518-1519, 1551-1553, 1569-1571)
+            pseq = create_polynomial_coarsening_sequence(degree)
+            hseq = create_geometric_coarsening_sequence(fine)
+            self.trias = hseq + [fine] * (len(pseq) - 1)
+            self.degrees = [pseq[0]] * len(hseq) + pseq[1:]
         else:
             raise MgamdError(f"Type '{mg_type}' not implemented")
         self.dofs = [DoFs(t, p, max_brick) for t, p in zip(self.trias, self.degrees)]

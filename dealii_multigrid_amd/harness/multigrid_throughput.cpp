@@ -5,7 +5,7 @@
 //
 //   ./multigrid_throughput input_0000.json [input_0001.json ...]
 //
-// Implemented `Type`s: HMG-global, PMG (global coarsening).  HMG-local/HPMG-local/AMG/AMGPETSc/HPMG raise
+// Implemented `Type`s: HMG-global, PMG, HPMG (global coarsening).  HMG-local/HPMG-local/AMG/AMGPETSc raise
 // "not implemented" exactly like the reference's AssertThrow(false, ExcNotImplemented()) for unknown strings.
 #include "../csrc/mgamd.hpp"
 
@@ -280,6 +280,18 @@ run(const Context &ctx, const RunParameters &params, ConvergenceTable &table)
     {
       degrees = create_polynomial_coarsening_sequence(params.fe_degree_fine);
       triangulations.assign(degrees.size(), tria);
+    }
+  else if (params.type == "HPMG")
+    {
+      // ref:multigrid_throughput.cc:1518-1519,1551-1553,1569-1571: h-levels at the lowest degree, then p-levels
+      const auto pseq = create_polynomial_coarsening_sequence(params.fe_degree_fine);
+      triangulations  = create_geometric_coarsening_sequence(tria);
+      degrees.assign(triangulations.size(), pseq.front());
+      for (size_t i = 1; i < pseq.size(); ++i)
+        {
+          triangulations.push_back(tria);
+          degrees.push_back(pseq[i]);
+        }
     }
   else
     throw std::runtime_error("Type '" + params.type + "': not implemented");

@@ -624,6 +624,14 @@ def build_hierarchy(geometry, n_ref_global, degree, mg_type="HMG-global", n_ref_
             seq.append(max(seq[-1] // 2, 1))
         degs = seq[::-1]
         meshes = [fine] * len(degs)
+    elif mg_type == "HPMG":  # ref:multigrid_throughput.cc:1518-1519,1551-1553,1569-1571
+        seq = [degree]
+        while seq[-1] > 1:
+            seq.append(max(seq[-1] // 2, 1))
+        pseq = seq[::-1]
+        hmeshes = coarsening_sequence(fine)
+        meshes = hmeshes + [fine] * (len(pseq) - 1)
+        degs = [pseq[0]] * len(hmeshes) + pseq[1:]
     else:
         raise ValueError(mg_type)
     levels = []

@@ -98,7 +98,8 @@ def test_chebyshev(mgamd, oracle, ctx, levels, geo, L, p, max_brick, degree):
 
 HIER_CASES = [("quadrant", 3, 1, "HMG-global"), ("quadrant", 4, 1, "HMG-global"), ("quadrant", 3, 2, "HMG-global"),
               ("quadrant", 3, 4, "HMG-global"), ("hypercube", 3, 1, "HMG-global"), ("hypercube", 2, 4, "HMG-global"),
-              ("annulus", 5, 2, "HMG-global"), ("quadrant", 3, 4, "PMG"), ("annulus", 5, 2, "PMG"), ("quadrant", 3, 3, "PMG")]
+              ("annulus", 5, 2, "HMG-global"), ("quadrant", 3, 4, "PMG"), ("annulus", 5, 2, "PMG"), ("quadrant", 3, 3, "PMG"),
+              ("quadrant", 3, 4, "HPMG"), ("annulus", 5, 2, "HPMG")]
 
 
 @pytest.fixture(scope="module")
