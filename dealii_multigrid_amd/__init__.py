@@ -481,7 +481,7 @@ class Hierarchy:
 
     def __init__(self, ctx: Context, geometry="quadrant", n_ref_global=3, degree=1, mg_type="HMG-global", n_ref_local=0,
                  smoother_degree=3, smoothing_range=20.0, eig_cg_n_iterations=20, coarse_solver="amg", number_type=F64,
-                 max_brick=0):
+                 max_brick=-1):
         self.ctx = ctx
         fine = Triangulation(geometry, n_ref_global, n_ref_local)
         if mg_type == "HMG-global":
@@ -499,6 +499,7 @@ class Hierarchy:
             self.degrees = [pseq[0]] * len(hseq) + pseq[1:]
         else:
             raise MgamdError(f"Type '{mg_type}' not implemented")
+        # max_brick=-1: bricks on large levels, single-cell slots on the latency-bound small ones (level_tables.hpp)
         self.dofs = [DoFs(t, p, max_brick) for t, p in zip(self.trias, self.degrees)]
         self.operators = [Operator(ctx, d, number_type) for d in self.dofs]
         self.transfers = [None] + [MGTwoLevelTransfer(self.operators[l], self.operators[l - 1]) for l in range(1, len(self.dofs))]
@@ -513,7 +514,7 @@ class DistributedHierarchy:
     rank's cells and exchange the partial sums of shared DoFs through `comm` (RCCL over xGMI in production)."""
 
     def __init__(self, ctx: Context, comm: Communicator, geometry="quadrant", n_ref_global=3, degree=1, smoother_degree=3,
-                 smoothing_range=20.0, eig_cg_n_iterations=20, coarse_solver="amg", number_type=F64, hanging_weight=2.0, max_brick=0):
+                 smoothing_range=20.0, eig_cg_n_iterations=20, coarse_solver="amg", number_type=F64, hanging_weight=2.0, max_brick=-1):
         self.ctx, self.comm = ctx, comm
         fine = Triangulation(geometry, n_ref_global)
         self.trias = create_geometric_coarsening_sequence(fine)

@@ -91,6 +91,15 @@ mgamd_tria_get_cells(const mgamd_tria *t, uint8_t *level, uint32_t *i, uint32_t 
   MGAMD_CATCH
 }
 
+static size_t
+n_nonempty_groups(const LevelTables &L)
+{
+  size_t n = 0;
+  for (const auto &g : L.groups)
+    n += g.n_slots() > 0;
+  return n;
+}
+
 int
 mgamd_dofs_create(const mgamd_tria *t, int degree, int max_brick, mgamd_dofs **out)
 {
@@ -101,7 +110,9 @@ mgamd_dofs_create(const mgamd_tria *t, int degree, int max_brick, mgamd_dofs **o
     throw std::invalid_argument("degree must be in [1," + std::to_string(MAX_DEGREE) + "]");
   auto *d   = new mgamd_dofs;
   d->tria   = t->tria;
-  d->tables = std::make_shared<LevelTables>(*d->tria, degree, max_brick);
+  d->tables = std::make_shared<LevelTables>(*d->tria, degree, std::max(max_brick, 0));
+  if (max_brick < 0 && is_small_level(d->tria->n_cells(), degree) && n_nonempty_groups(*d->tables) > 1)
+    d->tables = std::make_shared<LevelTables>(*d->tria, degree, 1);
   *out      = d;
   MGAMD_CATCH
 }
@@ -253,7 +264,11 @@ mgamd_dofs_create_local(const mgamd_partition *p, unsigned level, unsigned rank,
   try
     {
       if (p->part.replicated((int)level) || p->part.n_ranks == 1)
-        d->tables = std::make_shared<LevelTables>(*d->tria, degree, max_brick);
+        {
+          d->tables = std::make_shared<LevelTables>(*d->tria, degree, std::max(max_brick, 0));
+          if (max_brick < 0 && is_small_level(d->tria->n_cells(), degree) && n_nonempty_groups(*d->tables) > 1)
+            d->tables = std::make_shared<LevelTables>(*d->tria, degree, 1);
+        }
       else
         {
           const auto &owner = p->part.level_owner((int)level);
@@ -261,7 +276,9 @@ mgamd_dofs_create_local(const mgamd_partition *p, unsigned level, unsigned rank,
           for (size_t c = 0; c < owner.size(); ++c)
             (*d->owned)[c] = owner[c] == rank;
           d->shared = std::make_shared<std::map<uint64_t, SharedInfo>>(shared_keys(*d->tria, owner, p->part.n_ranks, (int)rank, degree));
-          d->tables = std::make_shared<LevelTables>(*d->tria, degree, max_brick, d->owned.get(), false, d->shared.get(), (int)rank);
+          d->tables = std::make_shared<LevelTables>(*d->tria, degree, std::max(max_brick, 0), d->owned.get(), false, d->shared.get(), (int)rank);
+          if (max_brick < 0 && is_small_level(d->tria->n_cells() / p->part.n_ranks, degree) && n_nonempty_groups(*d->tables) > 1)
+            d->tables = std::make_shared<LevelTables>(*d->tria, degree, 1, d->owned.get(), false, d->shared.get(), (int)rank);
           d->halo   = std::make_shared<HaloPlan>(make_halo_plan(*d->tables, *d->shared, p->part.n_ranks, (int)rank));
         }
     }

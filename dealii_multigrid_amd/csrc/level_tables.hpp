@@ -43,6 +43,17 @@ namespace mgamd
 {
   constexpr uint32_t INVALID_DOF = 0xFFFFFFFFu;
 
+  // max_brick = -1 ("auto"): levels below this many DoFs are latency-bound (a few microseconds per kernel whatever it
+  // does).  If such a level needs more than one slot group, it uses single-cell slots only: one lattice launch per
+  // operator application instead of one per brick size.  Measured on MI355X: -8 % V-cycle time for the octant at p=1
+  // (17 M DoFs) and p=4 (17.5 M DoFs); uniform meshes (one brick group per level anyway) keep their bricks.
+  constexpr size_t SMALL_LEVEL_DOFS = 500000;
+  inline bool
+  is_small_level(size_t n_cells, int p)
+  {
+    return n_cells * (size_t)(p * p * p) < SMALL_LEVEL_DOFS;
+  }
+
   inline int
   max_brick_for_degree(int p)
   {

@@ -108,11 +108,11 @@ namespace mgamd
   class DoFHandler
   {
   public:
-    DoFHandler(const std::shared_ptr<const Triangulation> &tria, unsigned fe_degree)
+    DoFHandler(const std::shared_ptr<const Triangulation> &tria, unsigned fe_degree, int max_brick = -1)
       : tria(tria)
     {
       mgamd_dofs *d = nullptr;
-      check(mgamd_dofs_create(tria->get(), (int)fe_degree, 0, &d));
+      check(mgamd_dofs_create(tria->get(), (int)fe_degree, max_brick, &d));
       h.reset(d, mgamd_dofs_destroy);
       check(mgamd_dofs_info(h.get(), &info));
     }

@@ -86,7 +86,8 @@ typedef struct
 /* DoFHandler::distribute_dofs(FE_Q(degree)) + zero Dirichlet on boundary id 0 + hanging-node
  * constraints + MatrixFree::reinit tables (ref:multigrid_throughput.cc:1578-1595,
  * ref:include/operator.h:24-47).  max_brick = 0 selects the largest brick that fits LDS;
- * max_brick = 1 disables bricks (every cell a generic slot). */
+ * max_brick = 1 disables bricks (every cell a generic slot); max_brick = -1 ("auto", what the
+ * harness and the hierarchies use) is 0 on large levels and 1 on latency-bound small ones. */
 int mgamd_dofs_create(const mgamd_tria *t, int degree, int max_brick, mgamd_dofs **out);
 int mgamd_dofs_destroy(mgamd_dofs *d);
 int mgamd_dofs_info(const mgamd_dofs *d, mgamd_dofs_info_t *info);

@@ -51,7 +51,7 @@ def key_based_chebyshev_start_vector():
 def test_sharded_solve_matches_single_rank(mgamd, geo, L, p, n_ranks):
     # single-rank reference on the same GPU, with the numbering-independent Chebyshev start vector of the sharded path
     ctx0 = mgamd.Context(0)
-    h0 = mgamd.Hierarchy(ctx0, geo, L, p, "HMG-global", coarse_solver="amg")
+    h0 = mgamd.Hierarchy(ctx0, geo, L, p, "HMG-global", coarse_solver="amg", max_brick=0)
     b0, x0 = h0.fine_operator.initialize_dof_vector(), h0.fine_operator.initialize_dof_vector()
     h0.fine_operator.rhs(b0)
     it0, res0 = mgamd.solve_cg(h0.fine_operator, h0.mg, x0, b0, 1e-4)
@@ -67,7 +67,7 @@ def test_sharded_solve_matches_single_rank(mgamd, geo, L, p, n_ranks):
     def rank_main(r):
         ctx = mgamd.Context(0)
         comm = group.comm(r)
-        h = mgamd.DistributedHierarchy(ctx, comm, geo, L, p, coarse_solver="amg")
+        h = mgamd.DistributedHierarchy(ctx, comm, geo, L, p, coarse_solver="amg", max_brick=0)
         keys = keyset(h.dofs[-1].keys())
         # operator application on consistent copies of a global vector
         u = h.fine_operator.initialize_dof_vector().from_host(np.array([uref[k] for k in keys]))

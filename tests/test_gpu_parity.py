@@ -109,7 +109,7 @@ def hierarchies(mgamd, oracle, ctx):
     def get(geo, L, p, mg_type, coarse="amg"):
         key = (geo, L, p, mg_type, coarse)
         if key not in cache:
-            h = mgamd.Hierarchy(ctx, geo, L, p, mg_type, coarse_solver=coarse)
+            h = mgamd.Hierarchy(ctx, geo, L, p, mg_type, coarse_solver=coarse, max_brick=0)
             keys = [d.keys() for d in h.dofs]
             levels, P = oracle.build_hierarchy(geo, L, p, mg_type, numbering_keys=keys)
             cache[key] = (h, levels, P)
@@ -213,7 +213,7 @@ def test_float_levels_mixed_precision(mgamd, oracle, ctx, geo, L, p, mg_type):
     """MGNumberType float (the reference's default, ref:multigrid_throughput.cc:2430-2433, ref:scripts/default.json:16):
     FP32 V-cycle under the FP64 outer CG.  Operator/transfer agree with the FP64 oracle to FP32 rounding, the
     preconditioned solve needs the same number of iterations and reaches the same solution to the CG tolerance."""
-    h = mgamd.Hierarchy(ctx, geo, L, p, mg_type, coarse_solver="amg", number_type=mgamd.F32)
+    h = mgamd.Hierarchy(ctx, geo, L, p, mg_type, coarse_solver="amg", number_type=mgamd.F32, max_brick=0)
     levels, P = oracle.build_hierarchy(geo, L, p, mg_type, numbering_keys=[d.keys() for d in h.dofs])
     rng = np.random.default_rng(21)
     for l, op in enumerate(h.operators):
@@ -238,3 +238,23 @@ def test_float_levels_mixed_precision(mgamd, oracle, ctx, geo, L, p, mg_type):
     it, res = mgamd.solve_cg(h.fine_operator, h.mg, x, b, 1e-4)
     assert abs(it - itref) <= 1
     assert rel_err(x.to_host(), xref) < 1e-3
+
+
+@pytest.mark.parametrize("geo,L,p", [("quadrant", 4, 2), ("quadrant", 5, 4)])
+def test_auto_slot_policy_same_vcycle(mgamd, ctx, geo, L, p, monkeypatch):
+    """max_brick=-1 (what bench and harness use: single-cell slots on small levels, bricks on large ones) only changes the
+    DoF numbering and the launch structure: the V-cycle is the same operator, compared through the DoF keys.  (The
+    eigenvalue-estimate start vector is index based, so it is switched to its numbering-independent key-hash form.)"""
+    monkeypatch.setenv("MGAMD_CHEB_KEY_INIT", "1")
+    ha = mgamd.Hierarchy(ctx, geo, L, p, "HMG-global", coarse_solver="amg", max_brick=-1)
+    hb = mgamd.Hierarchy(ctx, geo, L, p, "HMG-global", coarse_solver="amg", max_brick=0)
+    ka, kb = ha.dofs[-1].keys(), hb.dofs[-1].keys()
+    pos = {tuple(k): i for i, k in enumerate(kb.tolist())}
+    perm = np.array([pos[tuple(k)] for k in ka.tolist()])
+    rng = np.random.default_rng(5)
+    rb = rng.standard_normal(len(kb))
+    ra = rb[perm]
+    za, zb = mgamd.Vector(ctx, len(ka)), mgamd.Vector(ctx, len(kb))
+    ha.mg.vmult(za, mgamd.Vector(ctx, len(ka)).from_host(ra))
+    hb.mg.vmult(zb, mgamd.Vector(ctx, len(kb)).from_host(rb))
+    assert rel_err(za.to_host(), zb.to_host()[perm]) < 1e-11

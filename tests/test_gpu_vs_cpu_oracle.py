@@ -14,7 +14,7 @@ def test_solve_matches_cpu_oracle(mgamd, ctx, geo, L, p, typ):
     import cpu_oracle
 
     coarse = "amg" if typ == "HMG-global" else "cg_with_chebyshev"
-    h = mgamd.Hierarchy(ctx, geo, L, p, typ, coarse_solver=coarse)
+    h = mgamd.Hierarchy(ctx, geo, L, p, typ, coarse_solver=coarse, max_brick=0)
     levels, transfers, mg = cpu_oracle.build_from_dofs(h.dofs, mgamd.transfer_tables, coarse=coarse)
     n = h.n_dofs
     rng = np.random.default_rng(11)

@@ -14,7 +14,7 @@ cases = [tuple(c.split(":")) for c in sys.argv[1:]] or [("hypercube", "7", "1"),
 for geo, L, p in cases:
     L, p = int(L), int(p)
     t0 = time.time()
-    h = m.Hierarchy(ctx, geo, L, p, "HMG-global", coarse_solver="amg")
+    h = m.Hierarchy(ctx, geo, L, p, "HMG-global", coarse_solver="amg", max_brick=int(os.environ.get("MGAMD_MAX_BRICK", "-1")))
     ctx.synchronize()
     t1 = time.time()
     n = h.n_dofs
