@@ -6,6 +6,8 @@
 //                            one thread per lattice line and the line in registers, epilogue fused
 //                            (vmult / residual / Chebyshev update) for slot-interior DoFs, partial
 //                            sums of shell DoFs atomically added to the small 'tail' accumulator.
+// K1c cell_cluster_apply_kernel  the same operator on single cells at p = 1: one cell per thread, nodes deduplicated per
+//                            256-cell cluster in LDS (one load and one global atomic per distinct node).
 // K2  tail_kernel            same epilogue for the tail + constrained DoFs (identity rows).
 // K3  lattice_diag_kernel    diagonal of C^T K C (ref:include/operator.h:228-242).
 // K4  prolongate/restrict    MGTwoLevelTransfer embeddings (ref:multigrid_throughput.cc:1600-1604).
@@ -491,6 +493,196 @@ namespace mgamd
   }
 #undef MGAMD_STAMP
 #undef MGAMD_ABLATED
+
+  // K1c: the level operator on SINGLE CELLS at p = 1, one cell per thread, 256 consecutive (Morton) cells per
+  // workgroup (a CLUSTER).  The generic kernel spends one scattered load and one global atomic per (cell, node):
+  // 8 of each per cell at p = 1, which bounds it at ~35 G atomics/s (measured: removing the atomics halves its time).
+  // Here every distinct node of the cluster is loaded once into LDS, the cell operator runs in registers (2x2x2 lattice,
+  // hanging-node interpolation included), results are pre-reduced with LDS atomics and every distinct node costs ONE
+  // global atomic.  All nodes of such cells are tail DoFs, so the kernel is the same for every epilogue mode.
+  struct CellClusterDev
+  {
+    const uint32_t *uniq_ptr; // [n_clusters + 1] into uniq_idx
+    const uint32_t *uniq_idx; // global DoF index of every cluster-local node (ascending within a cluster)
+    const uint16_t *loc;      // [n_slots * 8] cluster-local id of lattice node x + 2y + 4z; 0xFFFF = constrained (zero, no scatter)
+    const uint16_t *mask;
+    const double   *h;
+    uint32_t        n_slots;
+    uint32_t        max_uniq; // LDS: 2 * max_uniq values
+  };
+  constexpr int CLUSTER_CELLS = 256;
+  constexpr int CLUSTER_ITERS = 8; // 256 cells x 8 nodes / 256 threads: the worst case, nothing shared
+
+  template <typename T>
+  struct ClusterArgs
+  {
+    CellClusterDev c;
+    Mats<1>        m;
+    const T       *src;
+    T             *tail_acc;
+    uint32_t       n_interior;
+  };
+
+  template <typename T, bool TRANSPOSE>
+  __device__ __forceinline__ void
+  hanging_in_registers_p1(T (&x)[8], const uint32_t mask, const Mats<1> &m)
+  {
+    const int  cx = mask & 1, cy = (mask >> 1) & 1, cz = (mask >> 2) & 1;
+    const bool fx = (mask >> 3) & 1, fy = (mask >> 4) & 1, fz = (mask >> 5) & 1;
+    const bool ex = (mask >> 6) & 1, ey = (mask >> 7) & 1, ez = (mask >> 8) & 1;
+#pragma unroll
+    for (int dd = 0; dd < 3; ++dd)
+      {
+        const int d = TRANSPOSE ? 2 - dd : dd;
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+            {
+              bool on;
+              int  c;
+              // same line classification as hanging_passes with P = 1
+              if (d == 0)
+                {
+                  const bool ou = u == cy, ov = v == cz;
+                  on            = (fy && ou) || (fz && ov) || (ex && ou && ov);
+                  c             = cx;
+                }
+              else if (d == 1)
+                {
+                  const bool ou = u == cx, ov = v == cz;
+                  on            = (fx && ou) || (fz && ov) || (ey && ou && ov);
+                  c             = cy;
+                }
+              else
+                {
+                  const bool ou = u == cx, ov = v == cy;
+                  on            = (fx && ou) || (fy && ov) || (ez && ou && ov);
+                  c             = cz;
+                }
+              const int i0 = d == 0 ? (v * 2 + u) * 2 : (d == 1 ? v * 4 + u : v * 2 + u);
+              const int i1 = i0 + (d == 0 ? 1 : (d == 1 ? 2 : 4));
+              if (on)
+                {
+                  const double *w  = c ? m.I1 : m.I0;
+                  const T       a0 = x[i0], a1 = x[i1];
+                  if (TRANSPOSE)
+                    {
+                      x[i0] = T(w[0]) * a0 + T(w[2]) * a1;
+                      x[i1] = T(w[1]) * a0 + T(w[3]) * a1;
+                    }
+                  else
+                    {
+                      x[i0] = T(w[0]) * a0 + T(w[1]) * a1;
+                      x[i1] = T(w[2]) * a0 + T(w[3]) * a1;
+                    }
+                }
+            }
+      }
+  }
+
+  template <typename T>
+  __global__ void
+  __launch_bounds__(CLUSTER_CELLS) cell_cluster_apply_kernel(const ClusterArgs<T> a)
+  {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    T *U   = reinterpret_cast<T *>(smem_raw);
+    T *Acc = U + a.c.max_uniq;
+
+    const int      tid  = threadIdx.x;
+    const uint32_t slot = blockIdx.x * CLUSTER_CELLS + tid;
+    const bool     act  = slot < a.c.n_slots;
+    const uint32_t p0   = a.c.uniq_ptr[blockIdx.x];
+    const int      nu   = (int)(a.c.uniq_ptr[blockIdx.x + 1] - p0);
+
+    // the cell's own table entries: requested first, consumed after the barrier
+    const uint4    lw   = reinterpret_cast<const uint4 *>(a.c.loc)[act ? slot : 0];
+    const uint32_t mask = act ? a.c.mask[slot] : 0u;
+    const T        h    = act ? T(a.c.h[slot]) : T(0);
+
+    // distinct nodes of the cluster -> LDS (all loads in flight before the first use)
+    uint32_t gi[CLUSTER_ITERS];
+    T        gv[CLUSTER_ITERS];
+#pragma unroll
+    for (int k = 0; k < CLUSTER_ITERS; ++k)
+      {
+        const int j = tid + k * CLUSTER_CELLS;
+        gi[k]       = nu > 0 ? a.c.uniq_idx[p0 + (j < nu ? j : nu - 1)] : a.n_interior;
+      }
+#pragma unroll
+    for (int k = 0; k < CLUSTER_ITERS; ++k)
+      gv[k] = a.src[gi[k]];
+#pragma unroll
+    for (int k = 0; k < CLUSTER_ITERS; ++k)
+      {
+        const int j = tid + k * CLUSTER_CELLS;
+        if (j < nu)
+          {
+            U[j]   = gv[k];
+            Acc[j] = T(0);
+          }
+      }
+    __syncthreads();
+
+    uint32_t      l[8];
+    const uint32_t lw4[4] = {lw.x, lw.y, lw.z, lw.w};
+    T             x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      {
+        l[i] = (lw4[i / 2] >> (16 * (i % 2))) & 0xFFFFu;
+        x[i] = (act && l[i] != 0xFFFFu) ? U[l[i]] : T(0);
+      }
+    if (mask >> 3)
+      hanging_in_registers_p1<T, false>(x, mask, a.m);
+    // three sweeps of the 2x2x2 lattice, as in lattice_sweeps
+    const T M0 = T(a.m.M[0]), M1 = T(a.m.M[1]), M2 = T(a.m.M[2]), M3 = T(a.m.M[3]);
+    const T K0 = T(a.m.K[0]), K1 = T(a.m.K[1]), K2 = T(a.m.K[2]), K3 = T(a.m.K[3]);
+    T       A[8], Bv[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      { // z lines: nodes q, q + 4
+        const T r0 = x[q], r1 = x[q + 4];
+        A[q]       = M0 * r0 + M1 * r1;
+        A[q + 4]   = M2 * r0 + M3 * r1;
+        Bv[q]      = K0 * r0 + K1 * r1;
+        Bv[q + 4]  = K2 * r0 + K3 * r1;
+      }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      { // y lines: nodes i0, i0 + 2 with i0 = x + 4z
+        const int i0 = (q & 1) + 4 * (q >> 1);
+        const T   a0 = A[i0], a1 = A[i0 + 2], b0 = Bv[i0], b1 = Bv[i0 + 2];
+        A[i0]        = M0 * a0 + M1 * a1;
+        A[i0 + 2]    = M2 * a0 + M3 * a1;
+        Bv[i0]       = K0 * a0 + K1 * a1 + M0 * b0 + M1 * b1;
+        Bv[i0 + 2]   = K2 * a0 + K3 * a1 + M2 * b0 + M3 * b1;
+      }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      { // x lines: nodes 2q, 2q + 1
+        const T a0 = A[2 * q], a1 = A[2 * q + 1], b0 = Bv[2 * q], b1 = Bv[2 * q + 1];
+        x[2 * q]     = h * (K0 * a0 + K1 * a1 + M0 * b0 + M1 * b1);
+        x[2 * q + 1] = h * (K2 * a0 + K3 * a1 + M2 * b0 + M3 * b1);
+      }
+    if (mask >> 3)
+      hanging_in_registers_p1<T, true>(x, mask, a.m);
+    if (act)
+      {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (l[i] != 0xFFFFu)
+            atomic_add(&Acc[l[i]], x[i]);
+      }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < CLUSTER_ITERS; ++k)
+      {
+        const int j = tid + k * CLUSTER_CELLS;
+        if (j < nu)
+          atomic_add(&a.tail_acc[gi[k] - a.n_interior], Acc[j]);
+      }
+  }
 
   // Diagonal of C^T K C.  Slots without hanging nodes: closed tensor form; single cells with hanging
   // faces/edges: one unit vector per local node through interpolation, sweeps and transpose.

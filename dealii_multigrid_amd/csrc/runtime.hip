@@ -275,6 +275,54 @@ namespace mgamd
     {
       return SlotGroupDev{interior_base.p, shell_idx.p, mask.p, h.p, shell_pos.p, (uint32_t)n_slots};
     }
+    // single cells at p = 1: per-cluster distinct node lists for cell_cluster_apply_kernel
+    DBuf<uint32_t> uniq_ptr, uniq_idx;
+    DBuf<uint16_t> loc;
+    uint32_t       max_uniq = 0;
+    bool
+    has_clusters() const
+    {
+      return uniq_ptr.p != nullptr;
+    }
+    CellClusterDev
+    cluster_view() const
+    {
+      return CellClusterDev{uniq_ptr.p, uniq_idx.p, loc.p, mask.p, h.p, (uint32_t)n_slots, max_uniq};
+    }
+    void
+    build_clusters(const SlotGroup &g)
+    {
+      const size_t          ns = g.n_slots(), ncl = (ns + CLUSTER_CELLS - 1) / CLUSTER_CELLS;
+      std::vector<uint32_t> ptr(ncl + 1, 0), idx;
+      std::vector<uint16_t> l(ns * 8, 0xFFFFu);
+      std::vector<uint32_t> tmp;
+      for (size_t c = 0; c < ncl; ++c)
+        {
+          const size_t s0 = c * CLUSTER_CELLS, s1 = std::min(ns, s0 + CLUSTER_CELLS);
+          tmp.clear();
+          for (size_t sl = s0; sl < s1; ++sl)
+            for (int s = 0; s < 8; ++s)
+              if (g.shell_idx[sl * 8 + s] != INVALID_DOF)
+                tmp.push_back(g.shell_idx[sl * 8 + s]);
+          std::sort(tmp.begin(), tmp.end());
+          tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+          for (size_t sl = s0; sl < s1; ++sl)
+            for (int s = 0; s < 8; ++s)
+              {
+                const uint32_t gi = g.shell_idx[sl * 8 + s];
+                if (gi != INVALID_DOF)
+                  l[sl * 8 + g.shell_pos[s]] = (uint16_t)(std::lower_bound(tmp.begin(), tmp.end(), gi) - tmp.begin());
+              }
+          idx.insert(idx.end(), tmp.begin(), tmp.end());
+          ptr[c + 1] = (uint32_t)idx.size();
+          max_uniq   = std::max<uint32_t>(max_uniq, (uint32_t)tmp.size());
+        }
+      if (idx.empty())
+        idx.push_back(0);
+      uniq_ptr.upload(ptr);
+      uniq_idx.upload(idx);
+      loc.upload(l);
+    }
   };
 
   template <typename T>
@@ -333,6 +381,8 @@ namespace mgamd
               d->mask.upload(g.mask);
               d->h.upload(g.h);
               d->shell_pos.upload(g.shell_pos);
+              if (p == 1 && g.B == 1 && !getenv("MGAMD_NO_CELL_CLUSTERS"))
+                d->build_clusters(g);
             }
           const size_t work = d->n_slots * (size_t)g.N * g.N * g.N;
           if (work > best)
@@ -431,6 +481,20 @@ namespace mgamd
       return m;
     }
 
+    void
+    launch_clusters(const GroupDev<T> &g, const T *src)
+    {
+      ClusterArgs<T> a;
+      a.c          = g.cluster_view();
+      a.m          = mats<1>();
+      a.src        = src;
+      a.tail_acc   = tail_acc.p;
+      a.n_interior = tables->n_interior;
+      const uint32_t grid = (uint32_t)((g.n_slots + CLUSTER_CELLS - 1) / CLUSTER_CELLS);
+      hipLaunchKernelGGL(cell_cluster_apply_kernel<T>, grid, CLUSTER_CELLS, 2 * (size_t)std::max<uint32_t>(g.max_uniq, 1) * sizeof(T), ctx->stream, a);
+      HIP_CHECK(hipGetLastError());
+    }
+
     template <int P, int MODE>
     void
     apply_P(const T *src, const Epilogue<T> &epi, bool diag, double words)
@@ -461,7 +525,10 @@ namespace mgamd
                 }
               HIP_CHECK(hipEventRecord(ctx->prof_events[ctx->prof_used].first, ctx->stream));
             }
-          dispatch_B<T, P, MODE>(ctx, g->B, a, diag);
+          if (P == 1 && !diag && g->has_clusters())
+            launch_clusters(*g, src);
+          else
+            dispatch_B<T, P, MODE>(ctx, g->B, a, diag);
           if (prof)
             {
               HIP_CHECK(hipEventRecord(ctx->prof_events[ctx->prof_used].second, ctx->stream));

@@ -7,7 +7,7 @@ import dealii_multigrid_amd as m
 geo, L, p = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 mode = int(os.environ["MGAMD_STAMPS"])
 ctx = m.Context(0)
-d = m.DoFs(m.Triangulation(geo, L), p)
+d = m.DoFs(m.Triangulation(geo, L), p, int(sys.argv[4]) if len(sys.argv) > 4 else 0)
 op = m.Operator(ctx, d)
 n = d.n_dofs
 x, y, b = (op.initialize_dof_vector() for _ in range(3))
