@@ -61,6 +61,7 @@ namespace mgamd
     const double   *h;
     const uint16_t *shell_pos;
     uint32_t        n_slots;
+    const uint32_t *fmask; // B == 2: family masks of constrained bricks (level_tables.hpp), nullptr if the group has none
   };
 
   enum ApplyMode
@@ -282,6 +283,78 @@ namespace mgamd
       }
   }
 
+  // Constrained 2^3 bricks (families with hanging faces/edges, level_tables.hpp): the parent's face/edge DoFs sit on
+  // the entity (parent coordinate c at lattice coordinate c, c = P at 2P); this embeds them in place along every lattice line that lies in a hanging face (or is
+  // a hanging edge), direction by direction (x, y, z), with E = [I0; I1]; transpose = the reverse.  One thread per
+  // line (sl, u, v) as in the sweeps.  Ends with a barrier.
+  template <typename T, int P>
+  __device__ __forceinline__ void
+  family_passes(T *__restrict__ buf, const Mats<P> &m, int sl, int u, int v, bool act, uint32_t fm, bool transpose)
+  {
+    constexpr int N  = 2 * P + 1;
+    constexpr int N3 = N * N * N;
+    constexpr int n  = P + 1;
+    const bool    xu = u == 0 || u == N - 1, xv = v == 0 || v == N - 1;
+    const int     su = u == N - 1, sv = v == N - 1;
+#pragma unroll
+    for (int dd = 0; dd < 3; ++dd)
+      {
+        const int d = transpose ? 2 - dd : dd;
+        // (u, v) are the coordinates in directions (e, f): d = 0: (y, z); d = 1: (x, z); d = 2: (x, y)
+        const int e = d == 0 ? 1 : 0, f = d == 2 ? 1 : 2;
+        // edge along d at sides (s1 of (d+1)%3, s2 of (d+2)%3)
+        const int s1 = d == 1 ? sv : su, s2 = d == 1 ? su : sv;
+        const bool on = act && fm &&
+                        (((u == 0 && ((fm >> (2 * e)) & 1)) || (u == N - 1 && ((fm >> (2 * e + 1)) & 1)) ||
+                          (v == 0 && ((fm >> (2 * f)) & 1)) || (v == N - 1 && ((fm >> (2 * f + 1)) & 1))) ||
+                         (xu && xv && ((fm >> (6 + 4 * d + s1 + 2 * s2)) & 1)));
+        const int base   = d == 0 ? sl * N3 + (v * N + u) * N : (d == 1 ? sl * N3 + v * N * N + u : sl * N3 + v * N + u);
+        const int stride = d == 0 ? 1 : (d == 1 ? N : N * N);
+        if (on)
+          {
+            if (!transpose)
+              {
+                T in[n], out[N];
+#pragma unroll
+                for (int b = 0; b < n; ++b)
+                  in[b] = buf[base + (b < P ? b : N - 1) * stride];
+#pragma unroll
+                for (int a = 0; a < N; ++a)
+                  {
+                    T acc = T(0);
+#pragma unroll
+                    for (int b = 0; b < n; ++b)
+                      acc += T(a <= P ? m.I0[a * n + b] : m.I1[(a - P) * n + b]) * in[b];
+                    out[a] = acc;
+                  }
+#pragma unroll
+                for (int a = 0; a < N; ++a)
+                  buf[base + a * stride] = out[a];
+              }
+            else
+              {
+                T in[N], out[n];
+#pragma unroll
+                for (int a = 0; a < N; ++a)
+                  in[a] = buf[base + a * stride];
+#pragma unroll
+                for (int b = 0; b < n; ++b)
+                  {
+                    T acc = T(0);
+#pragma unroll
+                    for (int a = 0; a < N; ++a)
+                      acc += T(a <= P ? m.I0[a * n + b] : m.I1[(a - P) * n + b]) * in[a];
+                    out[b] = acc;
+                  }
+#pragma unroll
+                for (int a = 0; a < N; ++a)
+                  buf[base + a * stride] = a < P ? out[a] : (a == N - 1 ? out[P] : T(0));
+              }
+          }
+        __syncthreads();
+      }
+  }
+
   template <typename T, int P>
   struct ApplyArgs
   {
@@ -451,11 +524,23 @@ namespace mgamd
           hanging_passes<T, P>(bufA, args.m, sl, u, v, act, mask, false);
       }
 
+    uint32_t fm = 0;
+    if (B == 2)
+      {
+        if (args.g.fmask != nullptr && act)
+          fm = args.g.fmask[slot0 + sl];
+        any_hanging = __syncthreads_or((int)(fm != 0)) != 0;
+        if (any_hanging)
+          family_passes<T, P>(bufA, args.m, sl, u, v, act, fm, false);
+      }
+
     if (!MGAMD_ABLATED(1))
       lattice_sweeps<T, P, B, BLOCK>(bufA, bufB, args.m, tid, nslots, args.g.h + slot0);
 
     if (B == 1 && any_hanging)
       hanging_passes<T, P>(bufA, args.m, sl, u, v, act, mask, true);
+    if (B == 2 && any_hanging)
+      family_passes<T, P>(bufA, args.m, sl, u, v, act, fm, true);
     MGAMD_STAMP(2)
 
     // ---- interior DoFs are complete: fused epilogue, contiguous stores -----------------------------------
@@ -764,6 +849,29 @@ namespace mgamd
               lattice_sweeps<T, P, B, G::BLOCK>(bufA, bufB, args.m, tid, nslots, args.g.h + slot0);
               hanging_passes<T, P>(bufA, args.m, sl, u, v, act, mask, true);
               if (act && ln == 0 && (mask >> 3))
+                bufD[sl * G::N3 + j] = bufA[sl * G::N3 + j];
+              __syncthreads();
+            }
+      }
+    if (B == 2)
+      {
+        // constrained families: the parent DoFs on hanging faces/edges need (C^T A C)_jj: one unit vector per shell
+        // position through embedding, sweeps and transpose (the other shell entries reproduce the closed form)
+        uint32_t fm = 0;
+        if (args.g.fmask != nullptr && act)
+          fm = args.g.fmask[slot0 + sl];
+        const bool any_family = __syncthreads_or((int)(fm != 0)) != 0;
+        if (any_family)
+          for (int s = 0; s < G::N_SHELL; ++s)
+            {
+              const int j = args.g.shell_pos[s];
+              for (int idx = tid; idx < G::SPW * G::N3; idx += G::BLOCK)
+                bufA[idx] = (idx % G::N3) == j ? T(1) : T(0);
+              __syncthreads();
+              family_passes<T, P>(bufA, args.m, sl, u, v, act, fm, false);
+              lattice_sweeps<T, P, B, G::BLOCK>(bufA, bufB, args.m, tid, nslots, args.g.h + slot0);
+              family_passes<T, P>(bufA, args.m, sl, u, v, act, fm, true);
+              if (act && ln == 0 && fm)
                 bufD[sl * G::N3 + j] = bufA[sl * G::N3 + j];
               __syncthreads();
             }

@@ -97,6 +97,7 @@ namespace mgamd
     std::vector<uint32_t> interior_base; // per slot: global index of its first interior DoF
     std::vector<uint32_t> shell_idx;     // per slot x n_shell: global DoF or INVALID_DOF (Dirichlet)
     std::vector<uint16_t> mask;          // per slot: constraint configuration (0 for bricks)
+    std::vector<uint32_t> fmask;         // B == 2 only, per slot: hanging faces/edges of the whole family (family_* helpers), 0 = none
     std::vector<double>   h;             // per slot: cell edge length
     std::vector<uint32_t> first_cell;    // per slot: index of its first cell in Tria::cells
     std::vector<uint16_t> shell_pos;     // n_shell: lattice index (z*N+y)*N+x of each shell entry
@@ -157,6 +158,149 @@ namespace mgamd
                 }
               for (int a = 0; a < n; ++a)
                 line[a * stride[d]] = tmp[a];
+            }
+      }
+  }
+
+  // ---- families with hanging nodes as constrained 2^3 bricks -------------------------------------------------
+  // The 8 children of one parent next to a coarser neighbour: the neighbour has the parent's size, so a hanging face of
+  // the family IS one face of the parent cell and its (2p+1)^2 lattice nodes are E (x) E times the parent face's
+  // (p+1)^2 DoFs, E = [I0; I1] the 1D two-cell embedding; a hanging edge likewise with one E.  The brick lattice stores
+  // the parent DoFs ON the entity: parent coordinate c < p along a free direction at lattice coordinate c, c = p at the
+  // far end 2p (so vertices and the nodes of edges shared by two hanging faces have ONE position, their own); the other
+  // positions of the entity carry no DoF.  The embedding runs in place, direction by direction, before the sweeps and
+  // its transpose after them.
+  // Family mask: bit 2*d + side = face with normal d hangs; bit 6 + 4*d + s1 + 2*s2 = edge along d hangs, s1/s2 the
+  // sides in directions (d+1)%3, (d+2)%3.
+  inline bool
+  family_face(uint32_t fm, int d, int side)
+  {
+    return (fm >> (2 * d + side)) & 1;
+  }
+  inline bool
+  family_edge(uint32_t fm, int d, int s1, int s2)
+  {
+    return (fm >> (6 + 4 * d + s1 + 2 * s2)) & 1;
+  }
+  // lattice node n (coordinates 0..2p) of a family: does it lie on a hanging face/edge?  pinned[d]: the coordinate
+  // is fixed by the hanging entity (its parent coordinate is 0 or p), otherwise it runs along the entity
+  inline bool
+  family_node_constrained(uint32_t fm, int p, const int n[3], bool pinned[3])
+  {
+    const int N1 = 2 * p;
+    bool      any = false;
+    for (int d = 0; d < 3; ++d)
+      {
+        pinned[d] = (n[d] == 0 && family_face(fm, d, 0)) || (n[d] == N1 && family_face(fm, d, 1));
+        any |= pinned[d];
+      }
+    if (any)
+      return true;
+    for (int d = 0; d < 3; ++d)
+      {
+        const int e = (d + 1) % 3, f = (d + 2) % 3;
+        if ((n[e] == 0 || n[e] == N1) && (n[f] == 0 || n[f] == N1) && family_edge(fm, d, n[e] == N1, n[f] == N1))
+          {
+            pinned[e] = pinned[f] = true;
+            return true;
+          }
+      }
+    return false;
+  }
+  // family mask from the children's cell masks (child index = position bits); false if they do not describe
+  // whole-family faces/edges
+  inline bool
+  family_mask_from_children(const uint16_t cm[8], int p, uint32_t &fm)
+  {
+    fm = 0;
+    for (int c = 0; c < 8; ++c)
+      {
+        const int cp[3] = {c & 1, (c >> 1) & 1, (c >> 2) & 1};
+        if ((cm[c] & 7) != c)
+          return false;
+        for (int d = 0; d < 3; ++d)
+          {
+            if ((cm[c] >> (MASK_FACE_SHIFT + d)) & 1)
+              fm |= 1u << (2 * d + cp[d]);
+            if ((cm[c] >> (MASK_EDGE_SHIFT + d)) & 1)
+              fm |= 1u << (6 + 4 * d + cp[(d + 1) % 3] + 2 * cp[(d + 2) % 3]);
+          }
+      }
+    // every child must see exactly the constraints the family mask implies
+    for (int c = 0; c < 8; ++c)
+      {
+        const int cp[3] = {c & 1, (c >> 1) & 1, (c >> 2) & 1};
+        for (int z = 0; z <= p; ++z)
+          for (int y = 0; y <= p; ++y)
+            for (int x = 0; x <= p; ++x)
+              {
+                const int a[3] = {x, y, z};
+                const int n[3] = {cp[0] * p + x, cp[1] * p + y, cp[2] * p + z};
+                bool      pinned[3];
+                const bool fam = family_node_constrained(fm, p, n, pinned);
+                bool       cell = false;
+                if (cm[c] >> MASK_FACE_SHIFT)
+                  {
+                    bool on[3];
+                    for (int d = 0; d < 3; ++d)
+                      on[d] = a[d] == cp[d] * p;
+                    for (int d = 0; d < 3; ++d)
+                      cell |= (((cm[c] >> (MASK_FACE_SHIFT + d)) & 1) && on[d]) ||
+                              (((cm[c] >> (MASK_EDGE_SHIFT + d)) & 1) && on[(d + 1) % 3] && on[(d + 2) % 3]);
+                  }
+                if (fam != cell)
+                  return false;
+              }
+      }
+    return true;
+  }
+  // the embedding (transpose = false) or its transpose on a (2p+1)^3 family lattice, host version
+  inline void
+  interpolate_family(const FE1D &fe, uint32_t fm, double *v, bool transpose)
+  {
+    if (!fm)
+      return;
+    const int p = fe.p, n = p + 1, N = 2 * p + 1;
+    const int stride[3] = {1, N, N * N};
+    double    in[2 * MAX_DEGREE + 1], out[2 * MAX_DEGREE + 1];
+    auto      E = [&](int a, int b) { return a <= p ? fe.I[0][a * n + b] : fe.I[1][(a - p) * n + b]; };
+    for (int dd = 0; dd < 3; ++dd)
+      {
+        const int d = transpose ? 2 - dd : dd, e = (d + 1) % 3, f = (d + 2) % 3;
+        for (int ae = 0; ae < N; ++ae)
+          for (int af = 0; af < N; ++af)
+            {
+              const bool xe = ae == 0 || ae == N - 1, xf = af == 0 || af == N - 1;
+              const bool on = (ae == 0 && family_face(fm, e, 0)) || (ae == N - 1 && family_face(fm, e, 1)) ||
+                              (af == 0 && family_face(fm, f, 0)) || (af == N - 1 && family_face(fm, f, 1)) ||
+                              (xe && xf && family_edge(fm, d, ae == N - 1, af == N - 1));
+              if (!on)
+                continue;
+              double *line = v + ae * stride[e] + af * stride[f];
+              for (int i = 0; i < N; ++i)
+                in[i] = line[i * stride[d]];
+              if (!transpose)
+                for (int a = 0; a < N; ++a)
+                  {
+                    double s = 0;
+                    for (int b = 0; b < n; ++b)
+                      s += E(a, b) * in[b < p ? b : N - 1];
+                    out[a] = s;
+                  }
+              else
+                {
+                  for (int i = 0; i < N; ++i)
+                    out[i] = 0;
+                  for (int b = 0; b < n; ++b)
+                    {
+                      double s = 0;
+                      for (int a = 0; a < N; ++a)
+                        s += E(a, b) * in[a];
+                      out[b < p ? b : N - 1] = s;
+                    }
+                }
+              for (int i = 0; i < N; ++i)
+                line[i * stride[d]] = out[i];
             }
       }
   }
@@ -265,6 +409,15 @@ namespace mgamd
       const uint16_t   mask = tria->masks[ci];
       if (constrained)
         *constrained = (mask >> MASK_FACE_SHIFT) ? node_on_constrained_entity(mask, p, a, parent_corner) : false;
+      if (g.B == 2 && g.fmask[s] && (mask >> MASK_FACE_SHIFT) && node_on_constrained_entity(mask, p, a))
+        {
+          // cell of a constrained family: the parent entity's DoF, as for a single cell
+          const int32_t *idx = keymap.find(resolved_key(ci, a));
+          if (!idx)
+            throw std::runtime_error("constrained family: parent DoF not numbered");
+          const uint32_t gi = (uint32_t)*idx;
+          return (gi >= n_interior + n_tail && gi < n_interior + n_tail + n_dirichlet) ? INVALID_DOF : gi;
+        }
       const int x = (c.i & (g.B - 1)) * p + a[0], y = (c.j & (g.B - 1)) * p + a[1], z = (c.k & (g.B - 1)) * p + a[2];
       const int N = g.N;
       if (x > 0 && y > 0 && z > 0 && x < N - 1 && y < N - 1 && z < N - 1)
@@ -338,6 +491,8 @@ namespace mgamd
                     loc[(z * N + y) * N + x] = h3 * m1[x] * m1[y] * m1[z];
               if (g.B == 1)
                 interpolate_hanging(fe, g.mask[s], loc.data(), true);
+              else if (g.B == 2 && g.fmask[s])
+                interpolate_family(fe, g.fmask[s], loc.data(), true);
               for (int z = 0; z < N; ++z)
                 for (int y = 0; y < N; ++y)
                   for (int x = 0; x < N; ++x)
@@ -379,7 +534,8 @@ namespace mgamd
       std::vector<int> sizes;
       // at p = 1 the 2^3 bricks are left to the single-cell cluster kernel, which is faster per cell than the lattice
       // kernel on 3^3 lattices and saves one launch per application (octant, 17 M DoFs: 2.93 -> 2.66 ms per V-cycle)
-      int skip = p == 1 ? 2 : 0;
+      const bool hanging_bricks = getenv("MGAMD_NO_HANGING_BRICKS") == nullptr;
+      int        skip           = p == 1 ? 2 : 0;
       if (const char *e = getenv("MGAMD_SKIP_BRICKS")) // development: bit mask of brick sizes to leave out
         skip = atoi(e);
       for (int B = Bmax; B >= 1; B /= 2)
@@ -420,16 +576,36 @@ namespace mgamd
                 }
               const Cell &c = cells[t];
               bool        ok;
+              uint32_t    fm = 0;
               if (B == 1)
                 ok = true;
               else
                 {
                   ok = c.level >= b && !(c.i & (B - 1)) && !(c.j & (B - 1)) && !(c.k & (B - 1)) && t + B3 <= nc;
+                  bool hanging = false;
                   for (size_t s = 0; ok && s < B3; ++s)
                     {
                       const Cell &d = cells[t + s];
                       ok = d.level == c.level && (d.i >> b) == (c.i >> b) && (d.j >> b) == (c.j >> b) && (d.k >> b) == (c.k >> b) &&
-                           !(masks[t + s] >> MASK_FACE_SHIFT) && cell_group[t + s] == 0xFF;
+                           cell_group[t + s] == 0xFF;
+                      hanging |= (masks[t + s] >> MASK_FACE_SHIFT) != 0;
+                    }
+                  if (ok && hanging)
+                    {
+                      // a family with hanging faces/edges can still be a (constrained) 2^3 brick
+                      ok = false;
+                      if (B == 2 && hanging_bricks && c.level >= 1)
+                        {
+                          uint16_t cm[8];
+                          bool     morton = true;
+                          for (int s = 0; s < 8; ++s)
+                            {
+                              const Cell &d = cells[t + s];
+                              cm[s]         = masks[t + s];
+                              morton &= (int)((d.i & 1) | ((d.j & 1) << 1) | ((d.k & 1) << 2)) == s;
+                            }
+                          ok = morton && family_mask_from_children(cm, p, fm);
+                        }
                     }
                 }
               if (!ok)
@@ -440,6 +616,8 @@ namespace mgamd
               const uint32_t slot = (uint32_t)g.first_cell.size();
               g.first_cell.push_back((uint32_t)t);
               g.mask.push_back(B == 1 ? masks[t] : 0);
+              if (B == 2)
+                g.fmask.push_back(fm);
               g.h.push_back(2.0 / (double)(1u << c.level));
               for (size_t s = 0; s < B3; ++s)
                 {
@@ -507,33 +685,55 @@ namespace mgamd
             {
               const int lin  = g.shell_pos[s];
               const int a[3] = {lin % g.N, (lin / g.N) % g.N, lin / (g.N * g.N)};
-              const uint64_t key = g.B == 1 ? resolved_key(ci, a) : own_key(anchor, a);
-              const int32_t  id  = classify(key, key_on_boundary(key) ? 1 : 0);
+              uint64_t key;
+              if (g.B == 1)
+                key = resolved_key(ci, a);
+              else if (g.B == 2 && g.fmask[r.slot])
+                {
+                  // hanging face/edge of a family: parent coordinate c sits at lattice coordinate c (c < p) or 2p (c = p),
+                  // the other lattice positions carry no DoF (filled by the embedding)
+                  bool pinned[3];
+                  if (family_node_constrained(g.fmask[r.slot], p, a, pinned))
+                    {
+                      int  ap[3];
+                      bool dof = true;
+                      for (int d = 0; d < 3; ++d)
+                        {
+                          ap[d] = (pinned[d] || a[d] == 2 * p) ? (a[d] ? p : 0) : a[d];
+                          dof &= pinned[d] || a[d] < p || a[d] == 2 * p;
+                        }
+                      if (!dof)
+                        {
+                          g.shell_idx[(size_t)r.slot * g.n_shell + s] = INVALID_DOF;
+                          continue;
+                        }
+                      key = own_key(Cell{c.i >> 1, c.j >> 1, c.k >> 1, (uint8_t)(c.level - 1)}, ap);
+                    }
+                  else
+                    key = own_key(anchor, a);
+                }
+              else
+                key = own_key(anchor, a);
+              const int32_t id = classify(key, key_on_boundary(key) ? 1 : 0);
               g.shell_idx[(size_t)r.slot * g.n_shell + s] = (uint32_t)id; // provisional
             }
         }
-      // own DoFs of hanging faces/edges
-      {
-        const SlotGroup &g = groups.back();
-        for (size_t s = 0; s < g.n_slots(); ++s)
-          if (g.mask[s] >> MASK_FACE_SHIFT)
-            {
-              const size_t ci = g.first_cell[s];
-              for (int z = 0; z <= p; ++z)
-                for (int y = 0; y <= p; ++y)
-                  for (int x = 0; x <= p; ++x)
+      // own DoFs of hanging faces/edges (single cells and cells of constrained families alike)
+      for (size_t ci = 0; ci < nc; ++ci)
+        if (cell_is_local(ci) && (masks[ci] >> MASK_FACE_SHIFT))
+          for (int z = 0; z <= p; ++z)
+            for (int y = 0; y <= p; ++y)
+              for (int x = 0; x <= p; ++x)
+                {
+                  const int a[3] = {x, y, z};
+                  bool      corner;
+                  if (node_on_constrained_entity(masks[ci], p, a, &corner) && !corner)
                     {
-                      const int a[3] = {x, y, z};
-                      bool      corner;
-                      if (node_on_constrained_entity(g.mask[s], p, a, &corner) && !corner)
-                        {
-                          const uint64_t key = own_key(cells[ci], a);
-                          if (!keymap.find(key))
-                            classify(key, 2);
-                        }
+                      const uint64_t key = own_key(cells[ci], a);
+                      if (!keymap.find(key))
+                        classify(key, 2);
                     }
-            }
-      }
+                }
       n_tail_owned      = counter[0];
       n_tail            = counter[0] + counter[3];
       n_dirichlet       = counter[1];
@@ -555,7 +755,7 @@ namespace mgamd
         }
       for (SlotGroup &g : groups)
         for (uint32_t &v : g.shell_idx)
-          v = (v >> 30) == 1 ? INVALID_DOF : final_index(v);
+          v = (v == INVALID_DOF || (v >> 30) == 1) ? INVALID_DOF : final_index(v);
     }
   };
 } // namespace mgamd

@@ -270,10 +270,11 @@ namespace mgamd
     DBuf<uint32_t> interior_base, shell_idx;
     DBuf<uint16_t> mask, shell_pos;
     DBuf<double>   h;
+    DBuf<uint32_t> fmask; // constrained 2^3 bricks, only if the group has any
     SlotGroupDev
     view() const
     {
-      return SlotGroupDev{interior_base.p, shell_idx.p, mask.p, h.p, shell_pos.p, (uint32_t)n_slots};
+      return SlotGroupDev{interior_base.p, shell_idx.p, mask.p, h.p, shell_pos.p, (uint32_t)n_slots, fmask.p};
     }
     // single cells at p = 1: per-cluster distinct node lists for cell_cluster_apply_kernel
     DBuf<uint32_t> uniq_ptr, uniq_idx;
@@ -381,6 +382,8 @@ namespace mgamd
               d->mask.upload(g.mask);
               d->h.upload(g.h);
               d->shell_pos.upload(g.shell_pos);
+              if (std::any_of(g.fmask.begin(), g.fmask.end(), [](uint32_t m) { return m != 0; }))
+                d->fmask.upload(g.fmask);
               if (p == 1 && g.B == 1 && !getenv("MGAMD_NO_CELL_CLUSTERS"))
                 d->build_clusters(g);
             }
