@@ -47,7 +47,10 @@ def run_workload(m, ctx, geometry, n_ref, degree, steps, warmup, barrier, sync, 
     for _ in range(max(warmup, 1)):
         h.mg.vmult(z, b)
     if profile:
-        ctx.kernel_profile(True)
+        # the dominant kernel symbol = the lattice kernel of the brick size with the most work on the finest level;
+        # all of its launches (on every level that has such bricks) are timed, like rocprofv3's per-symbol average
+        brick = max(h.dofs[-1].groups(), key=lambda g: g[1] * (degree * g[0] + 1) ** 3)[0]
+        ctx.kernel_profile(True, brick)
     barrier()
     sync()
     t0 = time.perf_counter()

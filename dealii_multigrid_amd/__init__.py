@@ -230,7 +230,8 @@ class Context:
         _chk(_lib.mgamd_ctx_stream(self._h, C.byref(s)))
         return s.value
 
-    def kernel_profile(self, enable: bool):
+    def kernel_profile(self, enable: bool, brick_size: int = 0):
+        _chk(_lib.mgamd_ctx_kernel_profile_brick(self._h, brick_size))
         _chk(_lib.mgamd_ctx_kernel_profile(self._h, 1 if enable else 0))
 
     def kernel_profile_read(self):

@@ -568,6 +568,15 @@ mgamd_ctx_kernel_profile(mgamd_ctx *ctx, int enable)
 }
 
 int
+mgamd_ctx_kernel_profile_brick(mgamd_ctx *ctx, int brick_size)
+{
+  MGAMD_TRY
+  REQUIRE(ctx);
+  ctx->ctx->prof_brick = brick_size;
+  MGAMD_CATCH
+}
+
+int
 mgamd_ctx_kernel_profile_read(mgamd_ctx *ctx, double *total_ms, uint64_t *n_launches, double *algorithmic_bytes)
 {
   MGAMD_TRY

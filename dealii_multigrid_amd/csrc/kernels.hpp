@@ -68,8 +68,11 @@ namespace mgamd
   {
     MODE_VMULT    = 0, // out = A x
     MODE_RESIDUAL = 1, // out = b - A x
-    MODE_CHEB     = 2, // out = x + f1 (x - xold) + f2 dinv (b - A x)      (xold == nullptr: xold = 0)
-    MODE_INVDIAG  = 3  // out = |d| > 1e-10 ? 1/d : 1                       (d delivered as 'A x')
+    MODE_CHEB     = 2, // out = x + f1 (x - xold) + f2 dinv (b - A x)      (xold == nullptr: xold = 0; Epilogue::from_b)
+    MODE_INVDIAG  = 3, // out = |d| > 1e-10 ? 1/d : 1                       (d delivered as 'A x')
+    // zero-start Chebyshev without materialising x_1 = c0 dinv b:
+    MODE_CHEB_FIRST  = 4, // MODE_CHEB with x := c0 dinv b computed on the fly (no x, no xold is read)
+    MODE_CHEB_SECOND = 5  // MODE_CHEB with xold := c0 dinv b computed on the fly
   };
 
   template <typename T>
@@ -81,7 +84,13 @@ namespace mgamd
     const T *b;
     const T *dinv;
     T        f1, f2;
+    T        c0; // MODE_CHEB_FIRST / MODE_CHEB_SECOND
   };
+  constexpr bool
+  is_cheb(int mode)
+  {
+    return mode == MODE_CHEB || mode == MODE_CHEB_FIRST || mode == MODE_CHEB_SECOND;
+  }
 
   template <typename T, int MODE>
   __device__ __forceinline__ void
@@ -458,8 +467,9 @@ namespace mgamd
           spos[it] = -1;
       }
     // ---- gather: values ---------------------------------------------------------------------------------
-    T xg[ITER]; // gathered interior values, kept for the Chebyshev epilogue
-    if (G::N_INT > 0 && !MGAMD_ABLATED(8))
+    constexpr bool x_from_b = MODE == MODE_CHEB_FIRST; // x = c0 dinv b, never stored
+    T              xg[ITER]; // gathered interior values, kept for the Chebyshev epilogue
+    if (G::N_INT > 0 && !MGAMD_ABLATED(8) && !x_from_b)
       {
 #pragma unroll
         for (int it = 0; it < ITER; ++it)
@@ -468,9 +478,26 @@ namespace mgamd
     T sval[ITERS];
     if (!MGAMD_ABLATED(16))
       {
+        if (x_from_b)
+          {
+            T sb[ITERS];
 #pragma unroll
-        for (int it = 0; it < ITERS; ++it)
-          sval[it] = args.src[sgi[it] != DEV_INVALID ? sgi[it] : 0];
+            for (int it = 0; it < ITERS; ++it)
+              {
+                const uint32_t gi = sgi[it] != DEV_INVALID ? sgi[it] : 0;
+                sval[it]          = args.epi.dinv[gi];
+                sb[it]            = args.epi.b[gi];
+              }
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it)
+              sval[it] = args.epi.c0 * sval[it] * sb[it];
+          }
+        else
+          {
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it)
+              sval[it] = args.src[sgi[it] != DEV_INVALID ? sgi[it] : 0];
+          }
       }
     // ---- epilogue operands, requested now, consumed after the sweeps ----------------------------------------
     T xo[ITER], bv[ITER], dv[ITER];
@@ -482,12 +509,24 @@ namespace mgamd
             xo[it] = bv[it] = dv[it] = T(0);
             if (MODE == MODE_RESIDUAL)
               bv[it] = args.epi.b[gbase[it]];
-            if (MODE == MODE_CHEB)
+            if (is_cheb(MODE))
               {
-                if (args.epi.xold)
+                if (MODE == MODE_CHEB && args.epi.xold)
                   xo[it] = args.epi.xold[gbase[it]];
                 bv[it] = args.epi.b[gbase[it]];
                 dv[it] = args.epi.dinv[gbase[it]];
+              }
+          }
+        if (MODE == MODE_CHEB_FIRST || MODE == MODE_CHEB_SECOND)
+          {
+#pragma unroll
+            for (int it = 0; it < ITER; ++it)
+              {
+                const T x1 = args.epi.c0 * dv[it] * bv[it];
+                if (MODE == MODE_CHEB_FIRST)
+                  xg[it] = x1;
+                else
+                  xo[it] = x1;
               }
           }
       }
@@ -609,6 +648,10 @@ namespace mgamd
     const T       *src;
     T             *tail_acc;
     uint32_t       n_interior;
+    // from_b = 1: the input is c0 dinv b (Epilogue::from_b), never stored
+    const T *b, *dinv;
+    T        c0;
+    int      from_b;
   };
 
   template <typename T, bool TRANSPOSE>
@@ -697,9 +740,25 @@ namespace mgamd
         const int j = tid + k * CLUSTER_CELLS;
         gi[k]       = nu > 0 ? a.c.uniq_idx[p0 + (j < nu ? j : nu - 1)] : a.n_interior;
       }
+    if (a.from_b == 1)
+      {
+        T gb[CLUSTER_ITERS];
 #pragma unroll
-    for (int k = 0; k < CLUSTER_ITERS; ++k)
-      gv[k] = a.src[gi[k]];
+        for (int k = 0; k < CLUSTER_ITERS; ++k)
+          {
+            gv[k] = a.dinv[gi[k]];
+            gb[k] = a.b[gi[k]];
+          }
+#pragma unroll
+        for (int k = 0; k < CLUSTER_ITERS; ++k)
+          gv[k] = a.c0 * gv[k] * gb[k];
+      }
+    else
+      {
+#pragma unroll
+        for (int k = 0; k < CLUSTER_ITERS; ++k)
+          gv[k] = a.src[gi[k]];
+      }
 #pragma unroll
     for (int k = 0; k < CLUSTER_ITERS; ++k)
       {
@@ -914,14 +973,14 @@ namespace mgamd
             ax[u] = xv[u] = xo[u] = bv[u] = dv[u] = T(0);
             if (i < total)
               {
-                if (MODE != MODE_INVDIAG && (MODE == MODE_CHEB || i >= n_tail))
+                if (MODE != MODE_INVDIAG && MODE != MODE_CHEB_FIRST && (is_cheb(MODE) || i >= n_tail))
                   xv[u] = epi.x[gi];
                 ax[u] = i < n_tail ? tail_acc[i] : xv[u];
-                if (MODE == MODE_RESIDUAL || MODE == MODE_CHEB)
+                if (MODE == MODE_RESIDUAL || is_cheb(MODE))
                   bv[u] = epi.b[gi];
-                if (MODE == MODE_CHEB)
+                if (is_cheb(MODE))
                   {
-                    if (epi.xold)
+                    if (MODE == MODE_CHEB && epi.xold)
                       xo[u] = epi.xold[gi];
                     dv[u] = epi.dinv[gi];
                   }
@@ -936,11 +995,23 @@ namespace mgamd
               {
                 if (i < n_tail)
                   tail_acc[i] = T(0);
+                if (MODE == MODE_CHEB_FIRST || MODE == MODE_CHEB_SECOND)
+                  {
+                    const T x1 = epi.c0 * dv[u] * bv[u];
+                    if (MODE == MODE_CHEB_FIRST)
+                      {
+                        xv[u] = x1;
+                        if (i >= n_tail)
+                          ax[u] = x1; // identity row
+                      }
+                    else
+                      xo[u] = x1;
+                  }
                 if (MODE == MODE_VMULT)
                   epi.out[gi] = ax[u];
                 else if (MODE == MODE_RESIDUAL)
                   epi.out[gi] = bv[u] - ax[u];
-                else if (MODE == MODE_CHEB)
+                else if (is_cheb(MODE))
                   epi.out[gi] = xv[u] + epi.f1 * (xv[u] - xo[u]) + epi.f2 * dv[u] * (bv[u] - ax[u]);
                 else
                   epi.out[gi] = (i < n_tail && fabs((double)ax[u]) > 1.0e-10) ? T(1) / ax[u] : T(1);

@@ -485,7 +485,7 @@ namespace mgamd
     }
 
     void
-    launch_clusters(const GroupDev<T> &g, const T *src)
+    launch_clusters(const GroupDev<T> &g, const T *src, const Epilogue<T> &epi, bool first)
     {
       ClusterArgs<T> a;
       a.c          = g.cluster_view();
@@ -493,6 +493,10 @@ namespace mgamd
       a.src        = src;
       a.tail_acc   = tail_acc.p;
       a.n_interior = tables->n_interior;
+      a.b          = epi.b;
+      a.dinv       = epi.dinv;
+      a.c0         = epi.c0;
+      a.from_b     = first ? 1 : 0;
       const uint32_t grid = (uint32_t)((g.n_slots + CLUSTER_CELLS - 1) / CLUSTER_CELLS);
       hipLaunchKernelGGL(cell_cluster_apply_kernel<T>, grid, CLUSTER_CELLS, 2 * (size_t)std::max<uint32_t>(g.max_uniq, 1) * sizeof(T), ctx->stream, a);
       HIP_CHECK(hipGetLastError());
@@ -516,7 +520,7 @@ namespace mgamd
             continue;
           a.g      = g->view();
           a.stamps = (stamps.p && g->B == prof_B && MODE == stamp_mode && !diag) ? stamps.p : nullptr;
-          const bool prof = ctx->profile && !diag && MODE == MODE_CHEB && g->B == prof_B;
+          const bool prof = ctx->profile && !diag && MODE == MODE_CHEB && g->B == (ctx->prof_brick ? ctx->prof_brick : prof_B);
           if (prof)
             {
               if (ctx->prof_used == ctx->prof_events.size())
@@ -529,7 +533,7 @@ namespace mgamd
               HIP_CHECK(hipEventRecord(ctx->prof_events[ctx->prof_used].first, ctx->stream));
             }
           if (P == 1 && !diag && g->has_clusters())
-            launch_clusters(*g, src);
+            launch_clusters(*g, src, epi, MODE == MODE_CHEB_FIRST);
           else
             dispatch_B<T, P, MODE>(ctx, g->B, a, diag);
           if (prof)
@@ -584,20 +588,26 @@ namespace mgamd
     void
     vmult_raw(T *dst, const T *src)
     {
-      Epilogue<T> e{dst, src, nullptr, nullptr, nullptr, T(0), T(0)};
+      Epilogue<T> e{dst, src, nullptr, nullptr, nullptr, T(0), T(0), T(0)};
       apply<MODE_VMULT>(src, e);
     }
     void
     residual_raw(T *t, const T *b, const T *x) // t = b - A x
     {
-      Epilogue<T> e{t, x, nullptr, b, nullptr, T(0), T(0)};
+      Epilogue<T> e{t, x, nullptr, b, nullptr, T(0), T(0), T(0)};
       apply<MODE_RESIDUAL>(x, e);
     }
     void
-    cheb_raw(T *out, const T *x, const T *xold, const T *b, const T *dinv, double f1, double f2)
+    cheb_raw(T *out, const T *x, const T *xold, const T *b, const T *dinv, double f1, double f2, int from_b = 0, double c0 = 0.0)
     {
-      Epilogue<T> e{out, x, xold, b, dinv, T(f1), T(f2)};
-      apply<MODE_CHEB>(x, e, false, xold ? 5.0 : 4.0);
+      // from_b = 1: x is c0 dinv b and xold = 0 (x is not read); from_b = 2: xold is c0 dinv b (xold is not read)
+      Epilogue<T> e{out, x, from_b ? nullptr : xold, b, dinv, T(f1), T(f2), T(c0)};
+      if (from_b == 1)
+        apply<MODE_CHEB_FIRST>(x, e, false, 3.0);
+      else if (from_b == 2)
+        apply<MODE_CHEB_SECOND>(x, e, false, 4.0);
+      else
+        apply<MODE_CHEB>(x, e, false, xold ? 5.0 : 4.0);
     }
 
     void
@@ -717,10 +727,12 @@ namespace mgamd
   {
     LevelOperator<T> *lop;
     DBuf<T>           dinv, tmp;
+    bool              fuse_first = true; // MGAMD_NO_FUSED_START=1: materialise x_1 (development A/B)
 
     Chebyshev(LevelOperator<T> *o, unsigned deg, double smoothing_range, unsigned eig_cg_n_iterations)
       : lop(o)
     {
+      fuse_first = getenv("MGAMD_NO_FUSED_START") == nullptr;
       op     = o;
       degree = deg;
       Ctx         *ctx = o->ctx;
@@ -843,8 +855,12 @@ namespace mgamd
       const size_t n   = lop->n_dofs();
       T           *cur = (degree % 2 == 1) ? S : Tb;
       T           *oth = (cur == S) ? Tb : S;
-      hipLaunchKernelGGL(vec_scaled_product_kernel<T>, grid_for(n), 256, 0, ctx->stream, cur, T(1.0 / theta), dinv.p, b, n);
-      if (degree >= 2 && std::fabs(delta) >= 1e-40)
+      // x_1 = D^-1 b / theta is only materialised when it is the result; the first operator pass computes it on the
+      // fly from b and D^-1 (which it reads anyway) and the second one uses it as x_old the same way
+      const bool passes = degree >= 2 && std::fabs(delta) >= 1e-40;
+      if (!passes || !fuse_first)
+        hipLaunchKernelGGL(vec_scaled_product_kernel<T>, grid_for(n), 256, 0, ctx->stream, cur, T(1.0 / theta), dinv.p, b, n);
+      if (passes)
         {
           double rhok = delta / theta, sigma = theta / delta;
           for (unsigned j = 0; j + 1 < degree; ++j)
@@ -852,7 +868,10 @@ namespace mgamd
               const double rhokp = 1.0 / (2.0 * sigma - rhok);
               const double f1 = rhokp * rhok, f2 = 2.0 * rhokp / delta;
               rhok = rhokp;
-              lop->cheb_raw(oth, cur, j == 0 ? nullptr : oth, b, dinv.p, f1, f2);
+              if (fuse_first && j < 2)
+                lop->cheb_raw(oth, j == 0 ? nullptr : cur, nullptr, b, dinv.p, f1, f2, (int)j + 1, 1.0 / theta);
+              else
+                lop->cheb_raw(oth, cur, j == 0 ? nullptr : oth, b, dinv.p, f1, f2);
               std::swap(cur, oth);
             }
         }

@@ -37,6 +37,7 @@ namespace mgamd
     double     *h_result  = nullptr; // pinned
     // dominant-kernel profiling (HIP events around the largest lattice_apply launches)
     bool                                           profile = false;
+    int                                            prof_brick = 0; // 0: the dominant group of each level; B: groups of B^3 bricks only
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
     size_t                                         prof_used  = 0;
     double                                         prof_bytes = 0.0;

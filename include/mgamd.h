@@ -236,6 +236,9 @@ int mgamd_solve_cg(mgamd_level_op *A, mgamd_mg *preconditioner, mgamd_vec *x, co
 /* per-kernel device time of the dominant kernel (cell operator) accumulated since the last reset,
  * measured with HIP events when profiling is enabled (bench.py roofline.achieved) */
 int mgamd_ctx_kernel_profile(mgamd_ctx *ctx, int enable);
+/* which launches are measured: brick_size = 0 (default) the slot group with the most work on every level;
+ * brick_size = B only groups of B^3-cell bricks, i.e. the launches of ONE kernel symbol (what rocprofv3 averages) */
+int mgamd_ctx_kernel_profile_brick(mgamd_ctx *ctx, int brick_size);
 int mgamd_ctx_kernel_profile_read(mgamd_ctx *ctx, double *total_ms, uint64_t *n_launches, double *algorithmic_bytes);
 
 #ifdef __cplusplus
