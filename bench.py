@@ -29,7 +29,9 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 
 
 def algorithmic_bytes_per_vcycle(n_dofs_per_level, k=3, word=8):
-    """s * [ (10k+3) * sum_{l>=1} N_l + 2 * sum_{l<L} N_l ]."""
+    """s * [ (10k+3) * sum_{l>=1} N_l + 2 * sum_{l<L} N_l ]  (the reference algorithm's compulsory
+    vector traffic with x_1 of the zero-start smoother stored; the implementation recomputes x_1 = D^-1 b / theta inside
+    the first two operator passes and moves 5 words per DoF and level fewer)."""
     N = n_dofs_per_level
     return word * ((10 * k + 3) * sum(N[1:]) + 2 * sum(N[:-1]))
 
@@ -209,13 +211,15 @@ def main():
     vcycle_gbs = (world if mode == "replicas" else 1) * prim["bytes_per_vcycle"] / (elapsed / args.steps) / 1e9 / world
     out["vcycle_algorithmic_GBps_per_gpu"] = vcycle_gbs
     out["vcycle_frac_of_hbm_peak"] = vcycle_gbs / HBM_PEAK_GBS
+    out["vcycle_bytes_model"] = "SURVEY 8(d): 8 B x [(10k+3) sum_{l>=1} N_l + 2 sum_{l<L} N_l], k=3"
     if prim["prof"] and prim["prof"][1] > 0:
         ms, n, by = prim["prof"]
         achieved = by / (ms * 1e-3) / 1e9
         B = max(prim["groups"], key=lambda g: g[1] * (4 * g[0] + 1) ** 3)[0]
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                            "traffic": pmc_traffic(args.nref, B),
-                           "kernel": f"lattice_apply_kernel<double,4,{B},MODE_CHEB> (all Chebyshev passes: 5 words/DoF with x_old, 4 without)",
+                           "kernel": f"lattice_apply_kernel<double,4,{B},MODE_CHEB> (the Chebyshev passes that read x and x_old from memory: "
+                                     f"5 words/DoF with x_old, 4 without; all launches of this symbol in the timed region)",
                            "launches": n, "avg_launch_us": ms / n * 1e3, "algorithmic_bytes_per_launch": by / n}
     if rank == 0 and not args.no_secondary:
         sec = run_workload(m, ctx, "quadrant", args.nref_p1, 1, args.steps, args.warmup, lambda: None, sync, profile=False)
