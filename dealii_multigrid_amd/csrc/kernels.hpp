@@ -437,6 +437,50 @@ namespace mgamd
     const int nslots = min((int)G::SPW, (int)args.g.n_slots - slot0);
     MGAMD_STAMP(0)
 
+    // D^-1 of slot-interior DoFs is not read from memory: they only see this slot's cells, so their diagonal is the
+    // closed tensor form  d = h (k_x m_y m_z + m_x k_y m_z + m_x m_y k_z)  of the assembled 1D diagonals (what
+    // lattice_diag_kernel stores), which depends on the node TYPE per direction only (t = lattice coordinate mod P:
+    // 0 = node shared by two cells, a = a-th interior node of a cell): a P^3 table of s = d/h and 1/s in LDS, and 1/h
+    // per slot.  One vector word less per interior DoF and Chebyshev pass.
+    // Used at P = 1 (one node type: the look-up is a broadcast, -11 % on the 17^3 kernel); at P = 4 the 64-entry look-up
+    // per entry pushes the 17^3 kernel over its 256 VGPRs (measured 1113 -> 1829 us), so D^-1 is read from memory there.
+    constexpr bool CLOSED_DINV = P == 1;
+    T *dtab = bufB + G::SPW * G::N3; // [P^3] s, [P^3] 1/s, [SPW] 1/h
+    if (CLOSED_DINV && is_cheb(MODE) && G::N_INT > 0)
+      {
+        constexpr int P3 = P * P * P;
+        for (int t = tid; t < P3; t += BLOCK)
+          {
+            const int tt[3] = {t % P, (t / P) % P, t / (P * P)};
+            T         m[3], k[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+              {
+                T dm = T(0), dk = T(0);
+                if (tt[d] == 0)
+                  { // last node of one cell + first node of the next
+                    dm = T(args.m.M[P * (P + 1) + P]) + T(args.m.M[0]);
+                    dk = T(args.m.K[P * (P + 1) + P]) + T(args.m.K[0]);
+                  }
+#pragma unroll
+                for (int q = 1; q < P; ++q)
+                  if (q == tt[d])
+                    {
+                      dm = T(args.m.M[q * (P + 1) + q]);
+                      dk = T(args.m.K[q * (P + 1) + q]);
+                    }
+                m[d] = dm;
+                k[d] = dk;
+              }
+            const T sv   = k[0] * m[1] * m[2] + m[0] * k[1] * m[2] + m[0] * m[1] * k[2];
+            dtab[t]      = sv;
+            dtab[P3 + t] = T(1) / sv;
+          }
+        for (int t = tid; t < nslots; t += BLOCK)
+          dtab[2 * P3 + t] = T(1) / T(args.g.h[slot0 + t]);
+        __syncthreads();
+      }
+
     // ---- gather: addresses ----------------------------------------------------------------------------
     uint32_t gbase[ITER]; // global index of interior entry `it` (always a valid address)
     int      glds[ITER];  // its LDS position, -1 if this thread has no entry `it`
@@ -499,14 +543,26 @@ namespace mgamd
               sval[it] = args.src[sgi[it] != DEV_INVALID ? sgi[it] : 0];
           }
       }
+    // D^-1 of this thread's interior entry `it` (see above); looked up where needed, never held in registers
+    auto interior_dinv = [&](int it) -> T {
+      constexpr int P3 = P * P * P;
+      bool          ok;
+      int           s2, i, lds;
+      IM::decode(tid + it * BLOCK, nslots, ok, s2, i, lds);
+      const int x = i % IM::NI_ + 1, y = (i / IM::NI_) % IM::NI_ + 1, z = i / (IM::NI_ * IM::NI_) + 1;
+      const int t = (x % P) + P * ((y % P) + P * (z % P));
+      const T   rh = dtab[2 * P3 + s2];
+      // |d| > 1e-10 ? 1/d : 1 with d = h s  (ref:include/operator.h:228-242)
+      return fabs((double)dtab[t]) > 1.0e-10 * fabs((double)rh) ? rh * dtab[P3 + t] : T(1);
+    };
     // ---- epilogue operands, requested now, consumed after the sweeps ----------------------------------------
-    T xo[ITER], bv[ITER], dv[ITER];
+    T xo[ITER], bv[ITER], dvm[CLOSED_DINV ? 1 : ITER]; // dvm: D^-1 from memory
     if (G::N_INT > 0 && !MGAMD_ABLATED(4))
       {
 #pragma unroll
         for (int it = 0; it < ITER; ++it)
           {
-            xo[it] = bv[it] = dv[it] = T(0);
+            xo[it] = bv[it] = T(0);
             if (MODE == MODE_RESIDUAL)
               bv[it] = args.epi.b[gbase[it]];
             if (is_cheb(MODE))
@@ -514,20 +570,15 @@ namespace mgamd
                 if (MODE == MODE_CHEB && args.epi.xold)
                   xo[it] = args.epi.xold[gbase[it]];
                 bv[it] = args.epi.b[gbase[it]];
-                dv[it] = args.epi.dinv[gbase[it]];
+                if (!CLOSED_DINV)
+                  dvm[it] = args.epi.dinv[gbase[it]];
               }
           }
-        if (MODE == MODE_CHEB_FIRST || MODE == MODE_CHEB_SECOND)
+        if (MODE == MODE_CHEB_FIRST)
           {
 #pragma unroll
             for (int it = 0; it < ITER; ++it)
-              {
-                const T x1 = args.epi.c0 * dv[it] * bv[it];
-                if (MODE == MODE_CHEB_FIRST)
-                  xg[it] = x1;
-                else
-                  xo[it] = x1;
-              }
+              xg[it] = args.epi.c0 * (CLOSED_DINV ? interior_dinv(it) : dvm[it]) * bv[it];
           }
       }
     // ---- gather: into LDS -------------------------------------------------------------------------------
@@ -596,7 +647,11 @@ namespace mgamd
               else if (MODE == MODE_RESIDUAL)
                 r = bv[it] - ax;
               else
-                r = xg[it] + args.epi.f1 * (xg[it] - xo[it]) + args.epi.f2 * dv[it] * (bv[it] - ax);
+                {
+                  const T dv  = CLOSED_DINV ? interior_dinv(it) : dvm[CLOSED_DINV ? 0 : it];
+                  const T xov = MODE == MODE_CHEB_SECOND ? args.epi.c0 * dv * bv[it] : xo[it];
+                  r           = xg[it] + args.epi.f1 * (xg[it] - xov) + args.epi.f2 * dv * (bv[it] - ax);
+                }
               args.epi.out[gbase[it]] = r;
             }
       }

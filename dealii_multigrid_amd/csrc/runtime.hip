@@ -208,7 +208,7 @@ namespace mgamd
       }
     else
       {
-        const size_t lds  = 2 * (size_t)G::SPW * G::N3 * sizeof(T);
+        const size_t lds  = (2 * (size_t)G::SPW * G::N3 + 2 * P * P * P + G::SPW) * sizeof(T);
         auto         kern = lattice_apply_kernel<T, P, B, MODE>;
         static bool  once = false;
         if (!once)
