@@ -22,6 +22,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef MGAMD_CLOSED_DINV_ALL
+#define MGAMD_CLOSED_DINV_ALL 0
+#endif
 namespace mgamd
 {
   constexpr uint32_t DEV_INVALID = 0xFFFFFFFFu;
@@ -444,7 +447,7 @@ namespace mgamd
     // per slot.  One vector word less per interior DoF and Chebyshev pass.
     // Used at P = 1 (one node type: the look-up is a broadcast, -11 % on the 17^3 kernel); at P = 4 the 64-entry look-up
     // per entry pushes the 17^3 kernel over its 256 VGPRs (measured 1113 -> 1829 us), so D^-1 is read from memory there.
-    constexpr bool CLOSED_DINV = P == 1;
+    constexpr bool CLOSED_DINV = MGAMD_CLOSED_DINV_ALL ? true : P == 1;
     T *dtab = bufB + G::SPW * G::N3; // [P^3] s, [P^3] 1/s, [SPW] 1/h
     if (CLOSED_DINV && is_cheb(MODE) && G::N_INT > 0)
       {
@@ -482,21 +485,38 @@ namespace mgamd
       }
 
     // ---- gather: addresses ----------------------------------------------------------------------------
-    uint32_t gbase[ITER]; // global index of interior entry `it` (always a valid address)
-    int      glds[ITER];  // its LDS position, -1 if this thread has no entry `it`
+    // interior entry `it` of this thread: global index (always a valid address) and LDS position (-1: no entry) with
+    // the node type for the D^-1 table in bits 16+.  With one slot per workgroup the global index is base + entry
+    // number and is not held in registers (the 17^3 kernels sit at the 256-VGPR limit).
+    constexpr bool REMAT = G::SPW == 1;
+    struct Ent
+    {
+      uint32_t g;
+      int      l, t;
+    };
+    const uint32_t base0 = G::N_INT > 0 ? args.g.interior_base[slot0] : 0u;
+    uint32_t       gbase[REMAT ? 1 : ITER];
+    int            glds[ITER];
     if (G::N_INT > 0)
       {
-        const uint32_t base0 = args.g.interior_base[slot0];
 #pragma unroll
         for (int it = 0; it < ITER; ++it)
           {
             bool ok;
             int  s2, i, lds;
             IM::decode(tid + it * BLOCK, nslots, ok, s2, i, lds);
-            gbase[it] = (G::SPW == 1 ? base0 : args.g.interior_base[slot0 + s2]) + i;
-            glds[it]  = ok ? lds : -1;
+            if (!REMAT)
+              gbase[REMAT ? 0 : it] = args.g.interior_base[slot0 + s2] + (uint32_t)i;
+            const int x = i % IM::NI_ + 1, y = (i / IM::NI_) % IM::NI_ + 1, z = i / (IM::NI_ * IM::NI_) + 1;
+            const int t = (x % P) + P * ((y % P) + P * (z % P));
+            glds[it]    = ok ? (lds | (t << 16) | (s2 << 24)) : -1;
           }
       }
+    auto ent = [&](int it) -> Ent {
+      const int      l = glds[it];
+      const uint32_t g = REMAT ? base0 + (uint32_t)(l >= 0 ? tid + it * BLOCK : 0) : gbase[REMAT ? 0 : it];
+      return Ent{g, l >= 0 ? (l & 0xFFFF) : -1, l >> 16};
+    };
     uint32_t sgi[ITERS];
     int      spos[ITERS];
 #pragma unroll
@@ -517,7 +537,7 @@ namespace mgamd
       {
 #pragma unroll
         for (int it = 0; it < ITER; ++it)
-          xg[it] = args.src[gbase[it]];
+          xg[it] = args.src[ent(it).g];
       }
     T sval[ITERS];
     if (!MGAMD_ABLATED(16))
@@ -546,12 +566,8 @@ namespace mgamd
     // D^-1 of this thread's interior entry `it` (see above); looked up where needed, never held in registers
     auto interior_dinv = [&](int it) -> T {
       constexpr int P3 = P * P * P;
-      bool          ok;
-      int           s2, i, lds;
-      IM::decode(tid + it * BLOCK, nslots, ok, s2, i, lds);
-      const int x = i % IM::NI_ + 1, y = (i / IM::NI_) % IM::NI_ + 1, z = i / (IM::NI_ * IM::NI_) + 1;
-      const int t = (x % P) + P * ((y % P) + P * (z % P));
-      const T   rh = dtab[2 * P3 + s2];
+      const int     gl = glds[it] >= 0 ? glds[it] : 0, t = (gl >> 16) & 0xFF, s2 = (gl >> 24) & 0x7F;
+      const T       rh = dtab[2 * P3 + s2];
       // |d| > 1e-10 ? 1/d : 1 with d = h s  (ref:include/operator.h:228-242)
       return fabs((double)dtab[t]) > 1.0e-10 * fabs((double)rh) ? rh * dtab[P3 + t] : T(1);
     };
@@ -562,16 +578,17 @@ namespace mgamd
 #pragma unroll
         for (int it = 0; it < ITER; ++it)
           {
+            const uint32_t g = ent(it).g;
             xo[it] = bv[it] = T(0);
             if (MODE == MODE_RESIDUAL)
-              bv[it] = args.epi.b[gbase[it]];
+              bv[it] = args.epi.b[g];
             if (is_cheb(MODE))
               {
                 if (MODE == MODE_CHEB && args.epi.xold)
-                  xo[it] = args.epi.xold[gbase[it]];
-                bv[it] = args.epi.b[gbase[it]];
+                  xo[it] = args.epi.xold[g];
+                bv[it] = args.epi.b[g];
                 if (!CLOSED_DINV)
-                  dvm[it] = args.epi.dinv[gbase[it]];
+                  dvm[it] = args.epi.dinv[g];
               }
           }
         if (MODE == MODE_CHEB_FIRST)
@@ -593,8 +610,11 @@ namespace mgamd
       {
 #pragma unroll
         for (int it = 0; it < ITER; ++it)
-          if (glds[it] >= 0)
-            bufA[glds[it]] = xg[it];
+          {
+            const int l = ent(it).l;
+            if (l >= 0)
+              bufA[l] = xg[it];
+          }
       }
     __syncthreads();
     MGAMD_STAMP(1)
@@ -638,9 +658,9 @@ namespace mgamd
       {
 #pragma unroll
         for (int it = 0; it < ITER; ++it)
-          if (glds[it] >= 0)
+          if (const Ent e = ent(it); e.l >= 0)
             {
-              const T ax = bufA[glds[it]];
+              const T ax = bufA[e.l];
               T       r;
               if (MODE == MODE_VMULT)
                 r = ax;
@@ -652,7 +672,7 @@ namespace mgamd
                   const T xov = MODE == MODE_CHEB_SECOND ? args.epi.c0 * dv * bv[it] : xo[it];
                   r           = xg[it] + args.epi.f1 * (xg[it] - xov) + args.epi.f2 * dv * (bv[it] - ax);
                 }
-              args.epi.out[gbase[it]] = r;
+              args.epi.out[e.g] = r;
             }
       }
     MGAMD_STAMP(3)
