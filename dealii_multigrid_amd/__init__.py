@@ -129,11 +129,12 @@ def create_polynomial_coarsening_sequence(degree: int):
 class Partition:
     """Domain decomposition of a level hierarchy over n_ranks GPUs."""
 
-    def __init__(self, trias, n_ranks: int, hanging_weight: float = 2.0):
+    def __init__(self, trias, n_ranks: int, hanging_weight: float = 2.0, min_root_cells: int = 0):
         self.trias, self.n_ranks = list(trias), n_ranks
         arr = (C.c_void_p * len(self.trias))(*[t._h for t in self.trias])
         self._h = C.c_void_p()
-        _chk(_lib.mgamd_partition_create(arr, len(self.trias), n_ranks, C.c_double(hanging_weight), C.byref(self._h)))
+        _chk(_lib.mgamd_partition_create_ex(arr, len(self.trias), n_ranks, C.c_double(hanging_weight), C.c_uint64(min_root_cells),
+                                            C.byref(self._h)))
         rl = C.c_uint()
         _chk(_lib.mgamd_partition_info(self._h, C.byref(rl), None))
         self.root_level = rl.value
@@ -515,11 +516,14 @@ class DistributedHierarchy:
     rank's cells and exchange the partial sums of shared DoFs through `comm` (RCCL over xGMI in production)."""
 
     def __init__(self, ctx: Context, comm: Communicator, geometry="quadrant", n_ref_global=3, degree=1, smoother_degree=3,
-                 smoothing_range=20.0, eig_cg_n_iterations=20, coarse_solver="amg", number_type=F64, hanging_weight=2.0, max_brick=-1):
+                 smoothing_range=20.0, eig_cg_n_iterations=20, coarse_solver="amg", number_type=F64, hanging_weight=2.0, max_brick=-1,
+                 min_root_dofs=1_000_000):
         self.ctx, self.comm = ctx, comm
         fine = Triangulation(geometry, n_ref_global)
         self.trias = create_geometric_coarsening_sequence(fine)
-        self.partition = Partition(self.trias, comm.n_ranks, hanging_weight)
+        # levels below ~1 M DoFs stay replicated: their single-GPU time (latency-bound, <= 0.3 ms) is below what the
+        # halo exchanges of a distributed level cost
+        self.partition = Partition(self.trias, comm.n_ranks, hanging_weight, min_root_dofs // degree ** 3)
         nl = len(self.trias)
         self.dofs = [DoFs(self.trias[l], degree, max_brick, self.partition, l, comm.rank) for l in range(nl)]
         self.operators = [Operator(ctx, self.dofs[l], number_type, comm if l >= self.partition.root_level and comm.n_ranks > 1 else None)

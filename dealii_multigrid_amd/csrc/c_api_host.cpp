@@ -193,6 +193,13 @@ mgamd_dofs_rhs_constant(const mgamd_dofs *d, double *out)
 int
 mgamd_partition_create(const mgamd_tria *const *trias, unsigned n_levels, unsigned n_ranks, double hanging_weight, mgamd_partition **out)
 {
+  return mgamd_partition_create_ex(trias, n_levels, n_ranks, hanging_weight, 0, out);
+}
+
+int
+mgamd_partition_create_ex(const mgamd_tria *const *trias, unsigned n_levels, unsigned n_ranks, double hanging_weight,
+                          uint64_t min_root_cells, mgamd_partition **out)
+{
   MGAMD_TRY
   if (!trias || !out || n_levels == 0 || n_ranks == 0)
     throw std::invalid_argument("bad argument");
@@ -207,7 +214,7 @@ mgamd_partition_create(const mgamd_tria *const *trias, unsigned n_levels, unsign
     }
   try
     {
-      p->part = make_partition(raw, (int)n_ranks, hanging_weight);
+      p->part = make_partition(raw, (int)n_ranks, hanging_weight, 32, (size_t)min_root_cells);
     }
   catch (...)
     {

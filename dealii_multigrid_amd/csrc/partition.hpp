@@ -38,14 +38,18 @@ namespace mgamd
   };
 
   inline Partition
-  make_partition(const std::vector<const Tria *> &trias, int n_ranks, double hanging_weight = 2.0, size_t min_cells_per_rank = 32)
+  make_partition(const std::vector<const Tria *> &trias, int n_ranks, double hanging_weight = 2.0, size_t min_cells_per_rank = 32,
+                 size_t min_root_cells = 0)
   {
+    // min_root_cells: levels with fewer cells stay replicated.  A distributed level pays a halo exchange per operator
+    // application (latency of a pack kernel + grouped send/recv + combine kernel) whatever its size, a replicated one
+    // only its own, latency-bound, single-GPU time.
     Partition P;
     P.n_ranks       = n_ranks;
     const int nl    = (int)trias.size();
     int       root  = nl - 1;
     for (int l = 1; l < nl; ++l)
-      if (trias[l]->n_cells() >= min_cells_per_rank * (size_t)n_ranks)
+      if (trias[l]->n_cells() >= min_cells_per_rank * (size_t)n_ranks && trias[l]->n_cells() >= min_root_cells)
         {
           root = l;
           break;

@@ -105,6 +105,10 @@ int mgamd_dofs_rhs_constant(const mgamd_dofs *d, double *out);
  * finer levels inherit the owner of their root ancestor, coarser levels are replicated on every rank. */
 int mgamd_partition_create(const mgamd_tria *const *trias, unsigned n_levels, unsigned n_ranks, double hanging_weight,
                            mgamd_partition **out);
+/* same, keeping every level with fewer than min_root_cells cells replicated (a distributed level pays one halo exchange
+ * per operator application whatever its size) */
+int mgamd_partition_create_ex(const mgamd_tria *const *trias, unsigned n_levels, unsigned n_ranks, double hanging_weight,
+                              uint64_t min_root_cells, mgamd_partition **out);
 int mgamd_partition_destroy(mgamd_partition *p);
 int mgamd_partition_info(const mgamd_partition *p, unsigned *root_level, unsigned *n_ranks);
 /* owner rank of every cell of a distributed level (level >= root_level) */

@@ -67,7 +67,7 @@ def test_sharded_solve_matches_single_rank(mgamd, geo, L, p, n_ranks):
     def rank_main(r):
         ctx = mgamd.Context(0)
         comm = group.comm(r)
-        h = mgamd.DistributedHierarchy(ctx, comm, geo, L, p, coarse_solver="amg", max_brick=0)
+        h = mgamd.DistributedHierarchy(ctx, comm, geo, L, p, coarse_solver="amg", max_brick=0, min_root_dofs=0)
         keys = keyset(h.dofs[-1].keys())
         # operator application on consistent copies of a global vector
         u = h.fine_operator.initialize_dof_vector().from_host(np.array([uref[k] for k in keys]))

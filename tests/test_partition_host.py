@@ -82,3 +82,16 @@ def test_partition_ownership_and_halo(mgamd, geo, L, p, n_ranks):
         owned_tail = d.info.n_tail_owned
         for ti, osrc in zip(pl["sh_tail"], pl["sh_owner_src"]):
             assert (osrc < 0) == (ti < owned_tail)
+
+
+def test_min_root_cells_keeps_small_levels_replicated(mgamd):
+    """levels with fewer cells than `min_root_cells` stay replicated (no halo exchange on latency-bound levels)"""
+    trias = mgamd.create_geometric_coarsening_sequence(mgamd.Triangulation("quadrant", 5))
+    default = mgamd.Partition(trias, 4)
+    assert default.root_level < len(trias) - 1
+    n_fine, n_prev = trias[-1].n_cells, trias[-2].n_cells
+    part = mgamd.Partition(trias, 4, 2.0, min_root_cells=n_prev + 1)
+    assert part.root_level == len(trias) - 1
+    assert mgamd.Partition(trias, 4, 2.0, min_root_cells=n_fine + 1).root_level == len(trias) - 1  # never beyond the finest
+    o = part.owner(len(trias) - 1)
+    assert set(np.unique(o)) == {0, 1, 2, 3}

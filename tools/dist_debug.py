@@ -34,7 +34,7 @@ group = m.SimGroup(n_ranks)
 res = [None] * n_ranks
 def main(rk):
     ctx = m.Context(0); comm = group.comm(rk)
-    h = m.DistributedHierarchy(ctx, comm, geo, L, p, coarse_solver="amg")
+    h = m.DistributedHierarchy(ctx, comm, geo, L, p, coarse_solver="amg", min_root_dofs=int(os.environ.get("MGAMD_MIN_ROOT_DOFS", "0")))
     out = []
     K = [ks(d.keys()) for d in h.dofs]
     for l in range(nl):
@@ -80,7 +80,7 @@ group2 = m.SimGroup(n_ranks)
 res2 = [None] * n_ranks
 def main2(rk):
     ctx = m.Context(0); comm = group2.comm(rk)
-    h = m.DistributedHierarchy(ctx, comm, geo, L, p, coarse_solver="amg")
+    h = m.DistributedHierarchy(ctx, comm, geo, L, p, coarse_solver="amg", min_root_dofs=int(os.environ.get("MGAMD_MIN_ROOT_DOFS", "0")))
     K = ks(h.dofs[-1].keys())
     def err(vals, table):
         a = np.array(vals); b = np.array([table[k] for k in K])

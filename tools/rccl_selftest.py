@@ -8,7 +8,7 @@ ctx = m.Context(0)
 uid = m.Communicator.rccl_unique_id()
 comm = m.Communicator.rccl(ctx, 1, 0, uid)
 print("allreduce(3.5) over 1 rank:", comm.allreduce_sum(ctx, 3.5))
-h = m.DistributedHierarchy(ctx, comm, "quadrant", 4, 2)
+h = m.DistributedHierarchy(ctx, comm, "quadrant", 4, 2, min_root_dofs=0)
 b, x = h.fine_operator.initialize_dof_vector(), h.fine_operator.initialize_dof_vector()
 h.fine_operator.rhs(b)
 print("n_dofs", h.n_dofs, "solve", m.solve_cg(h.fine_operator, h.mg, x, b, 1e-4))
