@@ -1232,7 +1232,9 @@ namespace mgamd
     std::vector<LevelOperator<T> *>  ops;
     std::vector<Transfer2<T> *>      tr;
     std::vector<Chebyshev<T> *>      sm;
-    std::vector<std::unique_ptr<DBuf<T>>> defect, S, Tb, res;
+    std::vector<std::unique_ptr<DBuf<T>>> defect, S, Tb, res; // defect: only the finest level owns memory,
+    DBuf<T>                               defect_slab;        // the coarser defects share one slab (ONE memset per cycle)
+    std::vector<T *>                      dptr;               // defect vector of every level
     std::vector<T *>                 sol; // where the level solution currently lives
     // per-cycle views of the finest level: when the outer vectors have the level number type, r IS the
     // finest defect and z is one of the two smoother buffers (no copy_to_mg / copy_from_mg traffic)
@@ -1267,18 +1269,34 @@ namespace mgamd
           S.emplace_back(new DBuf<T>);
           Tb.emplace_back(new DBuf<T>);
           res.emplace_back(new DBuf<T>);
-          defect[l]->alloc(n);
+          if (l + 1 == nl)
+            defect[l]->alloc(n);
           S[l]->alloc(n);
           Tb[l]->alloc(n);
           res[l]->alloc(n);
         }
+      {
+        // coarser defects: 256-byte aligned pieces of one allocation
+        std::vector<size_t> off(nl, 0);
+        size_t              total = 0;
+        for (unsigned l = 0; l + 1 < nl; ++l)
+          {
+            off[l] = total;
+            total += (ops[l]->n_dofs() + 31) / 32 * 32;
+          }
+        defect_slab.alloc(std::max<size_t>(total, 1));
+        dptr.assign(nl, nullptr);
+        for (unsigned l = 0; l + 1 < nl; ++l)
+          dptr[l] = defect_slab.p + off[l];
+        dptr[nl - 1] = defect[nl - 1]->p;
+      }
       sol.assign(nl, nullptr);
       dview.assign(nl, nullptr);
       sview.assign(nl, nullptr);
       tview.assign(nl, nullptr);
       for (unsigned l = 0; l < nl; ++l)
         {
-          dview[l] = defect[l]->p;
+          dview[l] = dptr[l];
           sview[l] = S[l]->p;
           tview[l] = Tb[l]->p;
         }
@@ -1429,10 +1447,10 @@ namespace mgamd
           stage(3, true, 0);
           const size_t n = ops[0]->n_dofs();
           if (coarse_type == "direct")
-            hipLaunchKernelGGL(dense_matvec_kernel<T>, (int)std::min<size_t>(n, 1024), 256, 0, ctx->stream, coarse_inv.p, defect[0]->p,
+            hipLaunchKernelGGL(dense_matvec_kernel<T>, (int)std::min<size_t>(n, 1024), 256, 0, ctx->stream, coarse_inv.p, dptr[0],
                                S[0]->p, (int)n);
           else
-            coarse_cg(S[0]->p, defect[0]->p, coarse_type == "cg_with_chebyshev");
+            coarse_cg(S[0]->p, dptr[0], coarse_type == "cg_with_chebyshev");
           sol[0] = S[0]->p;
           stage(3, false, 0);
           return;
@@ -1444,7 +1462,7 @@ namespace mgamd
       ops[l]->residual_raw(res[l]->p, dview[l], sview[l]); // t = d - A x
       stage(1, false, l);
       stage(2, true, l);
-      tr[l]->restrict_raw(defect[l - 1]->p, res[l]->p);
+      tr[l]->restrict_raw(dptr[l - 1], res[l]->p);
       stage(2, false, l);
       level_v_step(l - 1);
       stage(4, true, l);
@@ -1496,8 +1514,8 @@ namespace mgamd
           else
             hipLaunchKernelGGL((vec_copy_kernel<T, TO>), grid_for(n), 256, 0, ctx->stream, defect[L]->p, r, n);
         }
-      for (unsigned l = 0; l + 1 < nl; ++l)
-        defect[l]->zero(ctx->stream);
+      if (nl > 1)
+        defect_slab.zero(ctx->stream);
       if (cb)
         {
           ctx->sync();
