@@ -532,10 +532,11 @@ namespace mgamd
       const size_t nc    = cells.size();
       // ---- 1. slot decomposition
       std::vector<int> sizes;
-      // at p = 1 the 2^3 bricks are left to the single-cell cluster kernel, which is faster per cell than the lattice
-      // kernel on 3^3 lattices and saves one launch per application (octant, 17 M DoFs: 2.93 -> 2.66 ms per V-cycle)
+      // at p = 1 the 2^3 and 4^3 bricks are left to the single-cell cluster kernel, which is faster per cell than the
+      // lattice kernel on small lattices and saves a launch per size and application (octant, 17 M DoFs, measured:
+      // sizes {16,8,4,2,1} 2.93 ms per V-cycle, {16,8,4,1} 2.66, later {16,8,4,1} 2.31, {16,8,1} 2.23, {16,1} 2.29)
       const bool hanging_bricks = getenv("MGAMD_NO_HANGING_BRICKS") == nullptr;
-      int        skip           = p == 1 ? 2 : 0;
+      int        skip           = p == 1 ? 6 : 0;
       if (const char *e = getenv("MGAMD_SKIP_BRICKS")) // development: bit mask of brick sizes to leave out
         skip = atoi(e);
       for (int B = Bmax; B >= 1; B /= 2)
