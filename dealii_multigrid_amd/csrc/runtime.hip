@@ -1242,6 +1242,12 @@ namespace mgamd
     std::vector<T *>       sview, tview;
     std::string                      coarse_type;
     DBuf<double>                     coarse_inv; // dense inverse for "direct"
+    // The V-cycle restricted to levels 0..collapse_level is a fixed linear map of that level's defect (zero start): on
+    // levels this small every kernel is pure launch latency, so the map is tabulated once (n unit defects through the
+    // regular level code) and applied as ONE dense matvec.  Not used while stage callbacks are installed (the
+    // reference's per-level timers need the real stages).
+    unsigned     collapse_level = 0;
+    DBuf<double> collapse_M;
     DBuf<T>                          cg_r, cg_z, cg_p, cg_Ap;
     hipGraphExec_t                   graph_exec = nullptr;
     const void                      *graph_z = nullptr, *graph_r = nullptr;
@@ -1317,6 +1323,47 @@ namespace mgamd
         }
       else
         throw std::invalid_argument("CoarseGridSolverType '" + coarse + "' not implemented");
+      setup_collapse();
+    }
+
+    void
+    setup_collapse()
+    {
+      size_t max_n = 2048;
+      if (const char *e = getenv("MGAMD_COLLAPSE_MAX_DOFS")) // 0 disables
+        max_n = (size_t)atol(e);
+      unsigned lc = 0;
+      for (unsigned l = 1; l < nl; ++l)
+        if (ops[l]->n_dofs() <= max_n && !ops[l]->comm)
+          lc = l;
+        else
+          break;
+      if (lc == 0 || ops[0]->comm)
+        return;
+      const size_t        n = ops[lc]->n_dofs();
+      std::vector<T>      col(n);
+      std::vector<double> M(n * n);
+      const T             one = T(1);
+      for (size_t j = 0; j < n; ++j)
+        {
+          // unit defect on level lc (coarser defects zero), the regular cycle below it
+          if (lc + 1 < nl)
+            defect_slab.zero(ctx->stream);
+          else
+            {
+              HIP_CHECK(hipMemsetAsync(dptr[lc], 0, n * sizeof(T), ctx->stream));
+              if (nl > 1)
+                defect_slab.zero(ctx->stream);
+            }
+          HIP_CHECK(hipMemcpyAsync(dptr[lc] + j, &one, sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+          level_v_step(lc);
+          HIP_CHECK(hipMemcpyAsync(col.data(), sol[lc], n * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+          ctx->sync();
+          for (size_t r = 0; r < n; ++r)
+            M[r * n + j] = (double)col[r];
+        }
+      collapse_M.upload(M);
+      collapse_level = lc;
     }
 
     ~MultigridT() override
@@ -1453,6 +1500,14 @@ namespace mgamd
             coarse_cg(S[0]->p, dptr[0], coarse_type == "cg_with_chebyshev");
           sol[0] = S[0]->p;
           stage(3, false, 0);
+          return;
+        }
+      if (l == collapse_level && !cb)
+        {
+          const size_t n = ops[l]->n_dofs();
+          hipLaunchKernelGGL(dense_matvec_kernel<T>, (int)std::min<size_t>(n, 1024), 256, 0, ctx->stream, collapse_M.p, dview[l], sview[l],
+                             (int)n);
+          sol[l] = sview[l];
           return;
         }
       stage(0, true, l);

@@ -258,3 +258,19 @@ def test_auto_slot_policy_same_vcycle(mgamd, ctx, geo, L, p, monkeypatch):
     ha.mg.vmult(za, mgamd.Vector(ctx, len(ka)).from_host(ra))
     hb.mg.vmult(zb, mgamd.Vector(ctx, len(kb)).from_host(rb))
     assert rel_err(za.to_host(), zb.to_host()[perm]) < 1e-11
+
+
+@pytest.mark.parametrize("geo,L,p", [("quadrant", 4, 1), ("quadrant", 3, 4), ("annulus", 5, 2)])
+def test_collapsed_coarse_levels_same_vcycle(mgamd, ctx, geo, L, p, monkeypatch):
+    """Levels up to 2048 DoFs are applied as one precomputed dense matrix (the V-cycle below a level is a linear map of its
+    defect).  Same result as running those levels kernel by kernel, to rounding; with stage callbacks installed (the
+    harness) the real stages run."""
+    ha = mgamd.Hierarchy(ctx, geo, L, p, "HMG-global", coarse_solver="amg")
+    monkeypatch.setenv("MGAMD_COLLAPSE_MAX_DOFS", "0")
+    hb = mgamd.Hierarchy(ctx, geo, L, p, "HMG-global", coarse_solver="amg")
+    n = ha.n_dofs
+    r = np.random.default_rng(9).standard_normal(n)
+    za, zb = mgamd.Vector(ctx, n), mgamd.Vector(ctx, n)
+    ha.mg.vmult(za, mgamd.Vector(ctx, n).from_host(r))
+    hb.mg.vmult(zb, mgamd.Vector(ctx, n).from_host(r))
+    assert rel_err(za.to_host(), zb.to_host()) < 1e-12
