@@ -22,9 +22,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#ifndef MGAMD_CLOSED_DINV_ALL
-#define MGAMD_CLOSED_DINV_ALL 0
-#endif
 namespace mgamd
 {
   constexpr uint32_t DEV_INVALID = 0xFFFFFFFFu;
@@ -418,12 +415,11 @@ namespace mgamd
 #define MGAMD_ABLATED(bit) false
 #endif
 
+  // waves per SIMD: 2 for the 17^3 lattices (<= 256 VGPRs); 6 for single-cell slots (<= 80 VGPRs, measured 5 % faster at
+  // p = 4 than unconstrained with 110 VGPRs)
   template <typename T, int P, int B, int MODE>
-#ifndef MGAMD_B1_WAVES
-#define MGAMD_B1_WAVES 6 // single-cell slots: <= 80 VGPRs, measured 5 % faster at p = 4 than unconstrained (110 VGPRs)
-#endif
   __global__ void
-  __launch_bounds__((Geo<P, B>::ABLOCK), (Geo<P, B>::ROUNDS > 1 ? 2 : (B == 1 ? MGAMD_B1_WAVES : 1))) lattice_apply_kernel(const ApplyArgs<T, P> args)
+  __launch_bounds__((Geo<P, B>::ABLOCK), (Geo<P, B>::ROUNDS > 1 ? 2 : (B == 1 ? 6 : 1))) lattice_apply_kernel(const ApplyArgs<T, P> args)
   {
     using G  = Geo<P, B>;
     using IM = InteriorMap<P, B>;
@@ -447,7 +443,7 @@ namespace mgamd
     // per slot.  One vector word less per interior DoF and Chebyshev pass.
     // Used at P = 1 (one node type: the look-up is a broadcast, -11 % on the 17^3 kernel); at P = 4 the 64-entry look-up
     // per entry pushes the 17^3 kernel over its 256 VGPRs (measured 1113 -> 1829 us), so D^-1 is read from memory there.
-    constexpr bool CLOSED_DINV = MGAMD_CLOSED_DINV_ALL ? true : P == 1;
+    constexpr bool CLOSED_DINV = P == 1;
     T *dtab = bufB + G::SPW * G::N3; // [P^3] s, [P^3] 1/s, [SPW] 1/h
     if (CLOSED_DINV && is_cheb(MODE) && G::N_INT > 0)
       {
