@@ -1400,10 +1400,11 @@ namespace mgamd
     static constexpr int NC    = P * BC + 1;
     static constexpr int NF3   = NF * NF * NF;
     static constexpr int NC3   = NC * NC * NC;
-    static constexpr int S1    = NF * NC * NC; // after the z sweep
-    static constexpr int S2    = NF * NF * NC; // after the y sweep
     static constexpr int BLOCK = 256;
-    static constexpr int LDS   = NC3 + S1 + S2 + NF3;
+    // ONE lattice of NF^3 values: the coarse data sit at coordinates < NC and every sweep works IN PLACE (a thread reads
+    // its whole line into registers before it writes it back, lines of one sweep are disjoint).  39 KB at NF = 17, four
+    // workgroups per CU; with separate buffers per stage (77 KB, two per CU) the kernels were latency-bound at 1.9 TB/s.
+    static constexpr int LDS = NF3;
   };
 
   template <typename T, int P>
@@ -1461,10 +1462,7 @@ namespace mgamd
     using G  = BrickTransferGeo<P, B>;
     using LG = Geo<P, B>;
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    T *bufC = reinterpret_cast<T *>(smem_raw); // NC3
-    T *buf1 = bufC + G::NC3;                   // (Z, y, x): NF x NC x NC
-    T *buf2 = buf1 + G::S1;                    // (Z, Y, x): NF x NF x NC
-    T *bufF = buf2 + G::S2;                    // fine lattice NF3
+    T *buf = reinterpret_cast<T *>(smem_raw); // NF^3 lattice, index (z NF + y) NF + x
     constexpr int NC = G::NC, NF = G::NF, BLOCK = G::BLOCK;
     const int      tid   = threadIdx.x;
     const uint32_t brick = blockIdx.x;
@@ -1485,48 +1483,54 @@ namespace mgamd
         val[it] = args.src[gi[it] != DEV_INVALID ? gi[it] : 0];
 #pragma unroll
       for (int it = 0; it < ITC; ++it)
-        if (tid + it * BLOCK < G::NC3)
-          bufC[tid + it * BLOCK] = gi[it] != DEV_INVALID ? val[it] : T(0);
+        {
+          const int idx = tid + it * BLOCK;
+          if (idx < G::NC3)
+            {
+              const int x = idx % NC, y = (idx / NC) % NC, z = idx / (NC * NC);
+              buf[(z * NF + y) * NF + x] = gi[it] != DEV_INVALID ? val[it] : T(0);
+            }
+        }
     }
     __syncthreads();
     T in[NC], out[NF];
-    // z: lines (x,y) of the coarse lattice
+    // z: lines (x, y), x, y < NC
     for (int l = tid; l < NC * NC; l += BLOCK)
       {
-        const int x = l % NC, y = l / NC;
+        const int base = (l / NC) * NF + l % NC;
 #pragma unroll
         for (int i = 0; i < NC; ++i)
-          in[i] = bufC[(i * NC + y) * NC + x];
+          in[i] = buf[base + i * NF * NF];
         line_embed<T, P, G::BC>(args.E, in, out);
 #pragma unroll
         for (int i = 0; i < NF; ++i)
-          buf1[(i * NC + y) * NC + x] = out[i];
+          buf[base + i * NF * NF] = out[i];
       }
     __syncthreads();
-    // y: lines (x, Z)
+    // y: lines (x, Z), x < NC
     for (int l = tid; l < NC * NF; l += BLOCK)
       {
-        const int x = l % NC, Z = l / NC;
+        const int base = (l / NC) * NF * NF + l % NC;
 #pragma unroll
         for (int i = 0; i < NC; ++i)
-          in[i] = buf1[(Z * NC + i) * NC + x];
+          in[i] = buf[base + i * NF];
         line_embed<T, P, G::BC>(args.E, in, out);
 #pragma unroll
         for (int i = 0; i < NF; ++i)
-          buf2[(Z * NF + i) * NC + x] = out[i];
+          buf[base + i * NF] = out[i];
       }
     __syncthreads();
     // x: lines (Y, Z)
     for (int l = tid; l < NF * NF; l += BLOCK)
       {
-        const int Y = l % NF, Z = l / NF;
+        const int base = l * NF;
 #pragma unroll
         for (int i = 0; i < NC; ++i)
-          in[i] = buf2[(Z * NF + Y) * NC + i];
+          in[i] = buf[base + i];
         line_embed<T, P, G::BC>(args.E, in, out);
 #pragma unroll
         for (int i = 0; i < NF; ++i)
-          bufF[(Z * NF + Y) * NF + i] = out[i];
+          buf[base + i] = out[i];
       }
     __syncthreads();
     // dst += : interior contiguous, then the owned shell
@@ -1550,7 +1554,7 @@ namespace mgamd
             if (i < NIN_)
               {
                 const int x = i % NI_, y = (i / NI_) % NI_, z = i / (NI_ * NI_);
-                args.dst[base + i] = val[it] + bufF[((z + 1) * NF + (y + 1)) * NF + x + 1];
+                args.dst[base + i] = val[it] + buf[((z + 1) * NF + (y + 1)) * NF + x + 1];
               }
           }
       }
@@ -1570,7 +1574,7 @@ namespace mgamd
 #pragma unroll
       for (int it = 0; it < ITS; ++it)
         if (gi[it] != DEV_INVALID)
-          args.dst[gi[it]] = val[it] + bufF[args.shell_pos[tid + it * BLOCK]];
+          args.dst[gi[it]] = val[it] + buf[args.shell_pos[tid + it * BLOCK]];
     }
   }
 
@@ -1581,10 +1585,7 @@ namespace mgamd
     using G  = BrickTransferGeo<P, B>;
     using LG = Geo<P, B>;
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    T *bufC = reinterpret_cast<T *>(smem_raw);
-    T *buf1 = bufC + G::NC3;
-    T *buf2 = buf1 + G::S1;
-    T *bufF = buf2 + G::S2;
+    T *buf = reinterpret_cast<T *>(smem_raw); // NF^3 lattice, reduced in place to the coarse lattice at coordinates < NC
     constexpr int NC = G::NC, NF = G::NF, BLOCK = G::BLOCK;
     const int      tid   = threadIdx.x;
     const uint32_t brick = blockIdx.x;
@@ -1611,7 +1612,7 @@ namespace mgamd
             if (i < NIN_)
               {
                 const int x = i % NI_, y = (i / NI_) % NI_, z = i / (NI_ * NI_);
-                bufF[((z + 1) * NF + (y + 1)) * NF + x + 1] = val[it];
+                buf[((z + 1) * NF + (y + 1)) * NF + x + 1] = val[it];
               }
           }
       }
@@ -1631,47 +1632,47 @@ namespace mgamd
 #pragma unroll
       for (int it = 0; it < ITS; ++it)
         if (tid + it * BLOCK < LG::N_SHELL)
-          bufF[args.shell_pos[tid + it * BLOCK]] = gi[it] != DEV_INVALID ? val[it] : T(0);
+          buf[args.shell_pos[tid + it * BLOCK]] = gi[it] != DEV_INVALID ? val[it] : T(0);
     }
     __syncthreads();
     T in[NF], out[NC];
-    // x^T: lines (Y,Z)
+    // x^T: lines (Y, Z)
     for (int l = tid; l < NF * NF; l += BLOCK)
       {
-        const int Y = l % NF, Z = l / NF;
+        const int base = l * NF;
 #pragma unroll
         for (int i = 0; i < NF; ++i)
-          in[i] = bufF[(Z * NF + Y) * NF + i];
+          in[i] = buf[base + i];
         line_embed_T<T, P, G::BC>(args.E, in, out);
 #pragma unroll
         for (int i = 0; i < NC; ++i)
-          buf2[(Z * NF + Y) * NC + i] = out[i];
+          buf[base + i] = out[i];
       }
     __syncthreads();
-    // y^T: lines (x, Z)
+    // y^T: lines (x, Z), x < NC
     for (int l = tid; l < NC * NF; l += BLOCK)
       {
-        const int x = l % NC, Z = l / NC;
+        const int base = (l / NC) * NF * NF + l % NC;
 #pragma unroll
         for (int i = 0; i < NF; ++i)
-          in[i] = buf2[(Z * NF + i) * NC + x];
+          in[i] = buf[base + i * NF];
         line_embed_T<T, P, G::BC>(args.E, in, out);
 #pragma unroll
         for (int i = 0; i < NC; ++i)
-          buf1[(Z * NC + i) * NC + x] = out[i];
+          buf[base + i * NF] = out[i];
       }
     __syncthreads();
-    // z^T: lines (x, y)
+    // z^T: lines (x, y), x, y < NC
     for (int l = tid; l < NC * NC; l += BLOCK)
       {
-        const int x = l % NC, y = l / NC;
+        const int base = (l / NC) * NF + l % NC;
 #pragma unroll
         for (int i = 0; i < NF; ++i)
-          in[i] = buf1[(i * NC + y) * NC + x];
+          in[i] = buf[base + i * NF * NF];
         line_embed_T<T, P, G::BC>(args.E, in, out);
 #pragma unroll
         for (int i = 0; i < NC; ++i)
-          bufC[(i * NC + y) * NC + x] = out[i];
+          buf[base + i * NF * NF] = out[i];
       }
     __syncthreads();
     {
@@ -1694,7 +1695,9 @@ namespace mgamd
       for (int it = 0; it < ITC; ++it)
         if (gi[it] != DEV_INVALID)
           {
-            const T v = bufC[tid + it * BLOCK];
+            const int idx = tid + it * BLOCK;
+            const int x = idx % NC, y = (idx / NC) % NC, z = idx / (NC * NC);
+            const T   v = buf[(z * NF + y) * NF + x];
             if (inner[it])
               args.dst[gi[it]] = old[it] + v; // only this patch touches coarse nodes strictly inside it
             else
