@@ -33,6 +33,10 @@ namespace mgamd
     double K[(P + 1) * (P + 1)];
     double I0[(P + 1) * (P + 1)];
     double I1[(P + 1) * (P + 1)];
+    // even-odd decomposition of the centrosymmetric M and K (GLL nodes are symmetric): A x = Ae xe + Ao xo with
+    // xe_j = x_j + x_{P-j}, xo_j = x_j - x_{P-j};  Ae_ij = (A_ij + A_i,P-j)/2 (middle column: A_i,mid), Ao_ij = (A_ij - A_i,P-j)/2
+    static constexpr int NH = (P + 2) / 2, NO = (P + 1) / 2;
+    double               Me[NH * NH], Mo[NO * NO], Ke[NH * NH], Ko[NO * NO];
   };
 
   template <int P, int B>
@@ -138,6 +142,151 @@ namespace mgamd
           out[c * P + a] += T(Mc[a * (P + 1) + b]) * in[c * P + b];
   }
 
+  // ---- the same products through the even-odd decomposition: 13 multiply-adds instead of 25 per 5x5 block, and the
+  // even/odd splits of a line are shared by all products that use it (deal.II's sum factorisation does the same).
+  template <typename T, int P>
+  struct EvenOdd
+  {
+    static constexpr int NH = (P + 2) / 2, NO = (P + 1) / 2;
+    T                    e[NH], o[NO];
+    __device__ __forceinline__ void
+    split(const T *x) // x[0..P]
+    {
+#pragma unroll
+      for (int j = 0; j < NO; ++j)
+        {
+          e[j] = x[j] + x[P - j];
+          o[j] = x[j] - x[P - j];
+        }
+      if (NH > NO)
+        e[NH - 1] = x[NH - 1];
+    }
+    // this = Ae * xe, Ao * xo (accumulating if ACC)
+    template <bool ACC>
+    __device__ __forceinline__ void
+    apply(const double *__restrict__ Ae, const double *__restrict__ Ao, const EvenOdd &x)
+    {
+#pragma unroll
+      for (int i = 0; i < NH; ++i)
+        {
+          T acc = ACC ? e[i] : T(0);
+#pragma unroll
+          for (int j = 0; j < NH; ++j)
+            acc += T(Ae[i * NH + j]) * x.e[j];
+          e[i] = acc;
+        }
+#pragma unroll
+      for (int i = 0; i < NO; ++i)
+        {
+          T acc = ACC ? o[i] : T(0);
+#pragma unroll
+          for (int j = 0; j < NO; ++j)
+            acc += T(Ao[i * NO + j]) * x.o[j];
+          o[i] = acc;
+        }
+    }
+    // y[0..P] += recombination
+    __device__ __forceinline__ void
+    add_to(T *y) const
+    {
+#pragma unroll
+      for (int i = 0; i < NO; ++i)
+        {
+          y[i] += e[i] + o[i];
+          y[P - i] += e[i] - o[i];
+        }
+      if (NH > NO)
+        y[NH - 1] += e[NH - 1];
+    }
+  };
+
+  // outM = M a, outK = K a
+  template <typename T, int P, int B>
+  __device__ __forceinline__ void
+  line_MK(const Mats<P> &m, const T (&a)[P * B + 1], T (&outM)[P * B + 1], T (&outK)[P * B + 1])
+  {
+    if constexpr (P < 4) // no saving below 5x5 blocks
+      {
+        line_mult<T, P, B>(m.M, a, outM);
+        line_mult<T, P, B>(m.K, a, outK);
+        return;
+      }
+#pragma unroll
+    for (int i = 0; i < P * B + 1; ++i)
+      outM[i] = outK[i] = T(0);
+#pragma unroll
+    for (int c = 0; c < B; ++c)
+      {
+        EvenOdd<T, P> xa, y;
+        xa.split(&a[c * P]);
+        y.template apply<false>(m.Me, m.Mo, xa);
+        y.add_to(&outM[c * P]);
+        y.template apply<false>(m.Ke, m.Ko, xa);
+        y.add_to(&outK[c * P]);
+      }
+  }
+  // outM = M a, outS = K a + M b
+  template <typename T, int P, int B>
+  __device__ __forceinline__ void
+  line_M_KM(const Mats<P> &m, const T (&a)[P * B + 1], const T (&b)[P * B + 1], T (&outM)[P * B + 1], T (&outS)[P * B + 1])
+  {
+    if constexpr (P < 4)
+      {
+        T t[P * B + 1];
+        line_mult<T, P, B>(m.M, a, outM);
+        line_mult<T, P, B>(m.K, a, outS);
+        line_mult<T, P, B>(m.M, b, t);
+#pragma unroll
+        for (int i = 0; i < P * B + 1; ++i)
+          outS[i] += t[i];
+        return;
+      }
+#pragma unroll
+    for (int i = 0; i < P * B + 1; ++i)
+      outM[i] = outS[i] = T(0);
+#pragma unroll
+    for (int c = 0; c < B; ++c)
+      {
+        EvenOdd<T, P> xa, xb, y;
+        xa.split(&a[c * P]);
+        xb.split(&b[c * P]);
+        y.template apply<false>(m.Me, m.Mo, xa);
+        y.add_to(&outM[c * P]);
+        y.template apply<false>(m.Ke, m.Ko, xa);
+        y.template apply<true>(m.Me, m.Mo, xb);
+        y.add_to(&outS[c * P]);
+      }
+  }
+  // outS = K a + M b
+  template <typename T, int P, int B>
+  __device__ __forceinline__ void
+  line_KM(const Mats<P> &m, const T (&a)[P * B + 1], const T (&b)[P * B + 1], T (&outS)[P * B + 1])
+  {
+    if constexpr (P < 4)
+      {
+        T t[P * B + 1];
+        line_mult<T, P, B>(m.K, a, outS);
+        line_mult<T, P, B>(m.M, b, t);
+#pragma unroll
+        for (int i = 0; i < P * B + 1; ++i)
+          outS[i] += t[i];
+        return;
+      }
+#pragma unroll
+    for (int i = 0; i < P * B + 1; ++i)
+      outS[i] = T(0);
+#pragma unroll
+    for (int c = 0; c < B; ++c)
+      {
+        EvenOdd<T, P> xa, xb, y;
+        xa.split(&a[c * P]);
+        xb.split(&b[c * P]);
+        y.template apply<false>(m.Ke, m.Ko, xa);
+        y.template apply<true>(m.Me, m.Mo, xb);
+        y.add_to(&outS[c * P]);
+      }
+  }
+
   // The three sweeps.  Line l = tid + r*BLOCK (r < ROUNDS) of the workgroup is (slot sl, u, v) in every sweep.
   // bufA holds the input and receives the result; bufB is scratch.  Ends with a barrier.
   template <typename T, int P, int B, int BLOCK>
@@ -161,8 +310,7 @@ namespace mgamd
 #pragma unroll
             for (int i = 0; i < N; ++i)
               r0[i] = bufA[base + i * N * N];
-            line_mult<T, P, B>(m.M, r0, r1);
-            line_mult<T, P, B>(m.K, r0, r2);
+            line_MK<T, P, B>(m, r0, r1, r2);
 #pragma unroll
             for (int i = 0; i < N; ++i)
               {
@@ -183,18 +331,17 @@ namespace mgamd
 #pragma unroll
             for (int i = 0; i < N; ++i)
               r0[i] = bufA[base + i * N];
-            line_mult<T, P, B>(m.M, r0, r1);
-            line_mult<T, P, B>(m.K, r0, r2);
+            T rb[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              rb[i] = bufB[base + i * N];
+            line_M_KM<T, P, B>(m, r0, rb, r1, r2);
 #pragma unroll
             for (int i = 0; i < N; ++i)
               {
                 bufA[base + i * N] = r1[i];
-                r0[i]              = bufB[base + i * N];
+                bufB[base + i * N] = r2[i];
               }
-            line_mult<T, P, B>(m.M, r0, r1);
-#pragma unroll
-            for (int i = 0; i < N; ++i)
-              bufB[base + i * N] = r1[i] + r2[i];
           }
       }
     __syncthreads();
@@ -210,14 +357,13 @@ namespace mgamd
 #pragma unroll
             for (int i = 0; i < N; ++i)
               r0[i] = bufA[base + i];
-            line_mult<T, P, B>(m.K, r0, r1);
 #pragma unroll
             for (int i = 0; i < N; ++i)
-              r0[i] = bufB[base + i];
-            line_mult<T, P, B>(m.M, r0, r2);
+              r1[i] = bufB[base + i];
+            line_KM<T, P, B>(m, r0, r1, r2);
 #pragma unroll
             for (int i = 0; i < N; ++i)
-              bufA[base + i] = h * (r1[i] + r2[i]);
+              bufA[base + i] = h * r2[i];
           }
       }
     __syncthreads();

@@ -481,6 +481,17 @@ namespace mgamd
           m.I0[i] = tables->fe.I[0][i];
           m.I1[i] = tables->fe.I[1][i];
         }
+      constexpr int NH = Mats<P>::NH, NO = Mats<P>::NO;
+      auto          eo = [&](const double *A, double *Ae, double *Ao) {
+        for (int i = 0; i < NH; ++i)
+          for (int j = 0; j < NH; ++j)
+            Ae[i * NH + j] = (j < NO) ? 0.5 * (A[i * n + j] + A[i * n + P - j]) : A[i * n + j];
+        for (int i = 0; i < NO; ++i)
+          for (int j = 0; j < NO; ++j)
+            Ao[i * NO + j] = 0.5 * (A[i * n + j] - A[i * n + P - j]);
+      };
+      eo(m.M, m.Me, m.Mo);
+      eo(m.K, m.Ke, m.Ko);
       return m;
     }
 
