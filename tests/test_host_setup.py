@@ -166,3 +166,20 @@ def test_transfer_tables_reproduce_oracle_prolongation(mgamd, oracle, geo, L, p,
             assert not np.any(out[fi[n][ok]] != 0.0)  # every fine DoF owned by exactly one patch
             out[fi[n][ok]] += v[ok]
     assert np.abs(out - ref).max() < 1e-13 * max(np.abs(ref).max(), 1)
+
+
+@pytest.mark.parametrize("geo,L", [("quadrant", 4), ("annulus", 5), ("circle", 4), ("hypercube", 3)])
+@pytest.mark.parametrize("p", [1, 2, 3, 4])
+def test_slot_decomposition_covers_every_cell_once(mgamd, geo, L, p, monkeypatch):
+    """bricks (incl. constrained 2^3 families), and single cells partition the leaves; switching the constrained families
+    off only moves cells between the groups and never changes the DoF count"""
+    t = mgamd.Triangulation(geo, L)
+    d = mgamd.DoFs(t, p, 0)
+    assert sum(B ** 3 * n for B, n in d.groups()) == t.n_cells
+    monkeypatch.setenv("MGAMD_NO_HANGING_BRICKS", "1")
+    d0 = mgamd.DoFs(t, p, 0)
+    assert sum(B ** 3 * n for B, n in d0.groups()) == t.n_cells
+    assert d0.n_dofs == d.n_dofs and d0.info.n_hanging == d.info.n_hanging and d0.info.n_dirichlet == d.info.n_dirichlet
+    if p >= 2 and t.n_cells_hn > 0:
+        assert dict(d.groups())[1] <= dict(d0.groups())[1]  # families absorb single cells
+        assert d.info.n_interior >= d0.info.n_interior
