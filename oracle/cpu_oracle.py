@@ -52,6 +52,10 @@ def num_threads():
     return _lib.mgo_num_threads()
 
 
+def set_num_threads(n):
+    _lib.mgo_set_num_threads(int(n))
+
+
 class CpuLevel:
     def __init__(self, dofs):
         """dofs: dealii_multigrid_amd.DoFs (only its exported tables are used)."""
