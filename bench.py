@@ -226,12 +226,21 @@ def main():
                            "kernel": f"lattice_apply_kernel<double,4,{B},MODE_CHEB> (the Chebyshev passes that read x and x_old from memory: "
                                      f"5 words/DoF with x_old, 4 without; all launches of this symbol in the timed region)",
                            "launches": n, "avg_launch_us": ms / n * 1e3, "algorithmic_bytes_per_launch": by / n}
-    if rank == 0 and not args.no_secondary:
-        sec = run_workload(m, ctx, "quadrant", args.nref_p1, 1, args.steps, args.warmup, lambda: None, sync, profile=False)
-        t = sec["elapsed"] / args.steps
-        out["also"] = {"metric": "DoF/s per V-cycle, 3D octant p=1", "value": sec["n_dofs"] / t, "unit": "DoF/s", "n_gpus": 1,
-                       "ms_per_step": t * 1e3, "n_dofs": sec["n_dofs"], "NRefGlobal": args.nref_p1,
-                       "vcycle_frac_of_hbm_peak": sec["bytes_per_vcycle"] / t / 1e9 / HBM_PEAK_GBS, "cg_iterations_reltol_1e-4": sec["cg_iterations"]}
+    if not args.no_secondary and (rank == 0 or mode == "sharded"):
+        # octant p=1: on one GPU (rank 0), or sharded like the primary workload when that ran sharded
+        sharded2 = mode == "sharded"
+        sec = run_workload(m, ctx, "quadrant", args.nref_p1, 1, args.steps, args.warmup, barrier if sharded2 else (lambda: None), sync,
+                           profile=False, comm=comm if sharded2 else None)
+        t = sec["elapsed"]
+        if sharded2:
+            tt = torch.tensor([t], device="cuda", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t = float(tt.item())
+        t /= args.steps
+        out["also"] = {"metric": "DoF/s per V-cycle, 3D octant p=1", "value": sec["n_dofs"] / t, "unit": "DoF/s",
+                       "n_gpus": world if sharded2 else 1, "ms_per_step": t * 1e3, "n_dofs": sec["n_dofs"], "NRefGlobal": args.nref_p1,
+                       "vcycle_frac_of_hbm_peak": sec["bytes_per_vcycle"] / t / 1e9 / HBM_PEAK_GBS / (world if sharded2 else 1),
+                       "cg_iterations_reltol_1e-4": sec["cg_iterations"]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(m, "quadrant", args.cpu_nref, 4)
     barrier()
