@@ -173,6 +173,18 @@ class DoFs:
         _chk(_lib.mgamd_dofs_get_cell_dofs(self._h, _ptr(out)))
         return out
 
+    def rhs_function(self, kind: int):
+        """Operator::rhs for SimulationType kind (0 Constant, 1 Gaussian), host vector"""
+        b = np.zeros(self.n_dofs)
+        _chk(_lib.mgamd_dofs_rhs(self._h, kind, _ptr(b)))
+        return b
+
+    def distribute(self, x, kind: int):
+        """AffineConstraints::distribute on a host vector (Dirichlet values of `kind`, hanging-node interpolation)"""
+        x = np.ascontiguousarray(x, dtype=np.float64).copy()
+        _chk(_lib.mgamd_dofs_distribute(self._h, kind, _ptr(x)))
+        return x
+
     def rhs_constant(self):
         b = np.zeros(self.n_dofs)
         _chk(_lib.mgamd_dofs_rhs_constant(self._h, _ptr(b)))
@@ -379,8 +391,13 @@ class Operator:
     def compute_inverse_diagonal(self, diagonal: Vector):
         _chk(_lib.mgamd_level_op_inverse_diagonal(self._h, diagonal._h))
 
-    def rhs(self, b: Vector):
-        _chk(_lib.mgamd_level_op_rhs(self._h, b._h))
+    def rhs(self, b: Vector, kind: int = 0):
+        """Operator::rhs; kind = SimulationType (0 "Constant": f = 1, g = 0; 1 "Gaussian")"""
+        _chk(_lib.mgamd_level_op_rhs_kind(self._h, kind, b._h))
+
+    def distribute(self, x: Vector, kind: int = 0):
+        """constraints.distribute(solution): Dirichlet values of `kind`, hanging nodes interpolated"""
+        _chk(_lib.mgamd_level_op_distribute(self._h, kind, x._h))
 
     def __del__(self):
         if getattr(self, "_h", None):

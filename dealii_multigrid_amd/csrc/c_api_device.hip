@@ -362,6 +362,28 @@ mgamd_level_op_rhs(mgamd_level_op *op, mgamd_vec *rhs)
 }
 
 int
+mgamd_level_op_rhs_kind(mgamd_level_op *op, int kind, mgamd_vec *rhs)
+{
+  MGAMD_TRY
+  REQUIRE(op && rhs);
+  if (kind != 0 && kind != 1)
+    throw std::invalid_argument("SimulationType kind must be 0 (Constant) or 1 (Gaussian)");
+  op->op->rhs(*rhs, kind);
+  MGAMD_CATCH
+}
+
+int
+mgamd_level_op_distribute(mgamd_level_op *op, int kind, mgamd_vec *x)
+{
+  MGAMD_TRY
+  REQUIRE(op && x);
+  if (kind != 0 && kind != 1)
+    throw std::invalid_argument("SimulationType kind must be 0 (Constant) or 1 (Gaussian)");
+  op->op->distribute(*x, kind);
+  MGAMD_CATCH
+}
+
+int
 mgamd_level_op_debug_stamps(mgamd_level_op *op, unsigned long long *out, uint64_t max_count, uint64_t *count)
 {
   MGAMD_TRY

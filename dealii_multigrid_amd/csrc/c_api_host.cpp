@@ -179,6 +179,34 @@ mgamd_dofs_get_cell_dofs(const mgamd_dofs *d, uint32_t *out)
 }
 
 int
+mgamd_dofs_rhs(const mgamd_dofs *d, int kind, double *out)
+{
+  MGAMD_TRY
+  if (!d || !out)
+    throw std::invalid_argument("null argument");
+  if (kind != 0 && kind != 1)
+    throw std::invalid_argument("SimulationType kind must be 0 (Constant) or 1 (Gaussian)");
+  std::vector<double> b;
+  d->tables->compute_rhs_function(kind, b);
+  std::memcpy(out, b.data(), b.size() * sizeof(double));
+  MGAMD_CATCH
+}
+
+int
+mgamd_dofs_distribute(const mgamd_dofs *d, int kind, double *x)
+{
+  MGAMD_TRY
+  if (!d || !x)
+    throw std::invalid_argument("null argument");
+  if (kind != 0 && kind != 1)
+    throw std::invalid_argument("SimulationType kind must be 0 (Constant) or 1 (Gaussian)");
+  std::vector<double> v(x, x + d->tables->n_dofs);
+  d->tables->distribute(kind, v);
+  std::memcpy(x, v.data(), v.size() * sizeof(double));
+  MGAMD_CATCH
+}
+
+int
 mgamd_dofs_rhs_constant(const mgamd_dofs *d, double *out)
 {
   MGAMD_TRY

@@ -18,6 +18,7 @@
 //    DoFs of the *parent* face/edge in the same local slot and then interpolates in-cell with
 //    the 1D matrices FE1D::I[c]; its configuration is Tria::masks.
 #pragma once
+#include <cmath>
 #include <cstdlib>
 #include "fe1d.hpp"
 #include "octree.hpp"
@@ -506,6 +507,217 @@ namespace mgamd
                         b[idx] += loc[(z * N + y) * N + x];
                     }
             }
+        }
+    }
+
+    // ---- general data: SimulationType "Gaussian" (ref:multigrid_throughput.cc:60-125,2294-2298) -------------------
+    // u_exact = sum over centres of exp(-|x - c|^2 / w^2) / (sqrt(2 pi) w)^3, f = -Laplace u_exact; the reference uses
+    // one centre (-0.5,-0.5,-0.5) and w = 0.1.  kind 0: f = 1, g = 0 (the default "Constant").
+    static double
+    gaussian_solution(const double x[3])
+    {
+      const double w = 0.1, c[3] = {-0.5, -0.5, -0.5};
+      double       r2 = 0;
+      for (int d = 0; d < 3; ++d)
+        r2 += (x[d] - c[d]) * (x[d] - c[d]);
+      const double s = std::sqrt(2.0 * 3.14159265358979323846) * w;
+      return std::exp(-r2 / (w * w)) / (s * s * s);
+    }
+    static double
+    gaussian_rhs(const double x[3])
+    {
+      const double w = 0.1, c[3] = {-0.5, -0.5, -0.5};
+      double       r2 = 0;
+      for (int d = 0; d < 3; ++d)
+        r2 += (x[d] - c[d]) * (x[d] - c[d]);
+      const double s = std::sqrt(2.0 * 3.14159265358979323846) * w;
+      return (2.0 * 3 - 4.0 * r2 / (w * w)) / (w * w) * std::exp(-r2 / (w * w)) / (s * s * s);
+    }
+    static double
+    data_f(int kind, const double x[3])
+    {
+      return kind == 0 ? 1.0 : gaussian_rhs(x);
+    }
+    static double
+    data_g(int kind, const double x[3])
+    {
+      return kind == 0 ? 0.0 : gaussian_solution(x);
+    }
+    // position of the DoF that cell ci gathers at local node a (the parent's node on hanging entities)
+    void
+    gathered_node_position(size_t ci, const int a[3], double x[3]) const
+    {
+      const Cell    &c    = tria->cells[ci];
+      const uint16_t mask = tria->masks[ci];
+      const bool     par  = (mask >> MASK_FACE_SHIFT) && node_on_constrained_entity(mask, p, a);
+      const uint32_t ijk[3] = {c.i, c.j, c.k};
+      const int      lev  = par ? c.level - 1 : c.level;
+      const double   h    = 2.0 / (double)(1u << lev);
+      for (int d = 0; d < 3; ++d)
+        x[d] = -1.0 + h * ((double)(par ? ijk[d] >> 1 : ijk[d]) + fe.nodes[a[d]]);
+    }
+
+    // y = K_cell x on one cell's (p+1)^3 values (x fastest), h = cell size
+    void
+    cell_stiffness_apply(double h, const double *x, double *y) const
+    {
+      const int           n = p + 1, n3 = n * n * n;
+      std::vector<double> t1(n3), t2(n3), t3(n3);
+      auto                sweep = [&](const std::vector<double> &A, int d, const double *in, double *out) {
+        const int st = d == 0 ? 1 : (d == 1 ? n : n * n);
+        for (int i = 0; i < n3; ++i)
+          {
+            const int id = (i / st) % n;
+            double    s  = 0;
+            for (int b = 0; b < n; ++b)
+              s += A[id * n + b] * in[i + (b - id) * st];
+            out[i] = s;
+          }
+      };
+      for (int i = 0; i < n3; ++i)
+        y[i] = 0;
+      for (int dk = 0; dk < 3; ++dk)
+        { // K in direction dk, M in the others
+          sweep(dk == 0 ? fe.K : fe.M, 0, x, t1.data());
+          sweep(dk == 1 ? fe.K : fe.M, 1, t1.data(), t2.data());
+          sweep(dk == 2 ? fe.K : fe.M, 2, t2.data(), t3.data());
+          for (int i = 0; i < n3; ++i)
+            y[i] += h * t3[i];
+        }
+    }
+
+    // right-hand side for data `kind` (ref:include/operator.h:362-447): load vector by QGauss(p+1) quadrature of f,
+    // minus the operator without Dirichlet constraints applied to the boundary interpolant of g; constrained rows 0.
+    void
+    compute_rhs_function(int kind, std::vector<double> &b) const
+    {
+      if (kind == 0)
+        {
+          compute_rhs_constant(b);
+          return;
+        }
+      b.assign(n_dofs, 0.0);
+      const int           n = p + 1, n3 = n * n * n;
+      std::vector<double> fq(n3), t1(n3), t2(n3), load(n3), xg(n3), lift(n3);
+      for (size_t ci = 0; ci < tria->cells.size(); ++ci)
+        {
+          if (!cell_is_local(ci))
+            continue;
+          const Cell    &c    = tria->cells[ci];
+          const uint16_t mask = tria->masks[ci];
+          const double   h    = 2.0 / (double)(1u << c.level);
+          const double   o[3] = {-1.0 + h * c.i, -1.0 + h * c.j, -1.0 + h * c.k};
+          // f at the quadrature points, times JxW
+          for (int qz = 0; qz < n; ++qz)
+            for (int qy = 0; qy < n; ++qy)
+              for (int qx = 0; qx < n; ++qx)
+                {
+                  const double x[3] = {o[0] + h * fe.xq[qx], o[1] + h * fe.xq[qy], o[2] + h * fe.xq[qz]};
+                  fq[(qz * n + qy) * n + qx] = data_f(kind, x) * h * h * h * fe.wq[qx] * fe.wq[qy] * fe.wq[qz];
+                }
+          // integrate against the shape functions: load[a] = sum_q S[q][a] ... per direction
+          auto integrate = [&](int d, const double *in, double *out) {
+            const int st = d == 0 ? 1 : (d == 1 ? n : n * n);
+            for (int i = 0; i < n3; ++i)
+              {
+                const int id = (i / st) % n;
+                double    s  = 0;
+                for (int q = 0; q < n; ++q)
+                  s += fe.S[q * n + id] * in[i + (q - id) * st];
+                out[i] = s;
+              }
+          };
+          integrate(0, fq.data(), t1.data());
+          integrate(1, t1.data(), t2.data());
+          integrate(2, t2.data(), load.data());
+          // boundary interpolant of g on this cell's gathered DoFs, operator without Dirichlet constraints
+          bool any_g = false;
+          uint32_t idx[512];
+          for (int z = 0; z < n; ++z)
+            for (int y = 0; y < n; ++y)
+              for (int x = 0; x < n; ++x)
+                {
+                  const int a[3] = {x, y, z};
+                  const int t    = (z * n + y) * n + x;
+                  idx[t]         = cell_node_index(ci, a);
+                  xg[t]          = 0.0;
+                  if (idx[t] == INVALID_DOF)
+                    {
+                      double pos[3];
+                      gathered_node_position(ci, a, pos);
+                      xg[t] = data_g(kind, pos);
+                      any_g |= xg[t] != 0.0;
+                    }
+                }
+          if (any_g)
+            {
+              interpolate_hanging(fe, mask, xg.data(), false);
+              cell_stiffness_apply(h, xg.data(), lift.data());
+              for (int t = 0; t < n3; ++t)
+                load[t] -= lift[t];
+            }
+          interpolate_hanging(fe, mask, load.data(), true);
+          for (int t = 0; t < n3; ++t)
+            if (idx[t] != INVALID_DOF)
+              b[idx[t]] += load[t];
+        }
+      for (uint32_t i = first_constrained(); i < n_dofs; ++i)
+        b[i] = 0.0;
+    }
+
+    // constraints.distribute(x) for data `kind`: Dirichlet DoFs = g at their support point, hanging-node DoFs = the
+    // interpolant of their parent face/edge (x holds the solved free DoFs)
+    void
+    distribute(int kind, std::vector<double> &x) const
+    {
+      const int           n = p + 1, n3 = n * n * n;
+      std::vector<double> v(n3);
+      // Dirichlet values first (hanging nodes may depend on them)
+      for (size_t ci = 0; ci < tria->cells.size(); ++ci)
+        if (cell_is_local(ci))
+          for (int z = 0; z < n; ++z)
+            for (int y = 0; y < n; ++y)
+              for (int xx = 0; xx < n; ++xx)
+                {
+                  const int      a[3] = {xx, y, z};
+                  const uint64_t key  = resolved_key(ci, a);
+                  if (!key_on_boundary(key))
+                    continue;
+                  const int32_t *gi = keymap.find(key);
+                  if (gi && (uint32_t)*gi >= n_interior + n_tail && (uint32_t)*gi < n_interior + n_tail + n_dirichlet)
+                    {
+                      double pos[3];
+                      gathered_node_position(ci, a, pos);
+                      x[*gi] = data_g(kind, pos);
+                    }
+                }
+      for (size_t ci = 0; ci < tria->cells.size(); ++ci)
+        {
+          const uint16_t mask = tria->masks[ci];
+          if (!cell_is_local(ci) || !(mask >> MASK_FACE_SHIFT))
+            continue;
+          for (int z = 0; z < n; ++z)
+            for (int y = 0; y < n; ++y)
+              for (int xx = 0; xx < n; ++xx)
+                {
+                  const int      a[3] = {xx, y, z};
+                  const int32_t *gi   = keymap.find(resolved_key(ci, a));
+                  uint32_t       id   = cell_node_index(ci, a);
+                  if (id == INVALID_DOF && gi)
+                    id = (uint32_t)*gi; // Dirichlet DoF: its value was set above
+                  v[(z * n + y) * n + xx] = id != INVALID_DOF ? x[id] : 0.0;
+                }
+          interpolate_hanging(fe, mask, v.data(), false);
+          for (int z = 0; z < n; ++z)
+            for (int y = 0; y < n; ++y)
+              for (int xx = 0; xx < n; ++xx)
+                {
+                  const int a[3] = {xx, y, z};
+                  bool      corner;
+                  if (node_on_constrained_entity(mask, p, a, &corner) && !corner)
+                    if (const int32_t *own = keymap.find(own_key(tria->cells[ci], a)))
+                      x[*own] = v[(z * n + y) * n + xx];
+                }
         }
     }
 

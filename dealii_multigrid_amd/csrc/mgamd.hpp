@@ -280,10 +280,17 @@ namespace mgamd
         initialize_dof_vector(diagonal);
       check(mgamd_level_op_inverse_diagonal(h.get(), diagonal.get()));
     }
+    // simulation_kind: 0 "Constant" (f = 1, g = 0), 1 "Gaussian" (ref:multigrid_throughput.cc:2286-2298)
     void
-    rhs(Vector &system_rhs) const
+    rhs(Vector &system_rhs, int simulation_kind = 0) const
     {
-      check(mgamd_level_op_rhs(h.get(), system_rhs.get()));
+      check(mgamd_level_op_rhs_kind(h.get(), simulation_kind, system_rhs.get()));
+    }
+    // constraints.distribute(solution)
+    void
+    distribute(Vector &solution, int simulation_kind = 0) const
+    {
+      check(mgamd_level_op_distribute(h.get(), simulation_kind, solution.get()));
     }
     mgamd_level_op *
     get() const

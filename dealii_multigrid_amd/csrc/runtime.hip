@@ -164,12 +164,37 @@ namespace mgamd
   }
 
   void
-  LevelOperatorBase::rhs(mgamd_vec &b)
+  LevelOperatorBase::distribute(mgamd_vec &x, int kind)
+  {
+    if (x.n != n_dofs())
+      throw std::invalid_argument("distribute: vector size mismatch");
+    std::vector<double> h(x.n);
+    ctx->sync();
+    if (x.type == MGAMD_F64)
+      HIP_CHECK(hipMemcpy(h.data(), x.data, h.size() * 8, hipMemcpyDeviceToHost));
+    else
+      {
+        std::vector<float> f(x.n);
+        HIP_CHECK(hipMemcpy(f.data(), x.data, f.size() * 4, hipMemcpyDeviceToHost));
+        std::copy(f.begin(), f.end(), h.begin());
+      }
+    tables->distribute(kind, h);
+    if (x.type == MGAMD_F64)
+      HIP_CHECK(hipMemcpy(x.data, h.data(), h.size() * 8, hipMemcpyHostToDevice));
+    else
+      {
+        std::vector<float> f(h.begin(), h.end());
+        HIP_CHECK(hipMemcpy(x.data, f.data(), f.size() * 4, hipMemcpyHostToDevice));
+      }
+  }
+
+  void
+  LevelOperatorBase::rhs(mgamd_vec &b, int kind)
   {
     if (b.n != n_dofs())
       throw std::invalid_argument("rhs: vector size mismatch");
     std::vector<double> h;
-    tables->compute_rhs_constant(h);
+    tables->compute_rhs_function(kind, h);
     if (b.type == MGAMD_F64)
       HIP_CHECK(hipMemcpyAsync(b.data, h.data(), h.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     else

@@ -178,7 +178,9 @@ namespace mgamd
     virtual size_t
     read_debug_stamps(unsigned long long *out, size_t max_count) = 0;
     void
-    rhs(mgamd_vec &b);
+    rhs(mgamd_vec &b, int kind = 0);
+    void
+    distribute(mgamd_vec &x, int kind);
   };
 
   struct ChebyshevBase

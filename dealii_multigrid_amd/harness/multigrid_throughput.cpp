@@ -245,8 +245,13 @@ run(const Context &ctx, const RunParameters &params, ConvergenceTable &table)
           pre("CellWeightPolicy") || pre("FirstChildPolicy")))
       throw std::runtime_error("PartitionerName '" + policy + "': not implemented");
   }
-  if (params.simulation_type != "Constant")
-    throw std::runtime_error("SimulationType '" + params.simulation_type + "': not implemented (f = 1, g = 0 only)");
+  int simulation_kind; // ref:multigrid_throughput.cc:2286-2300
+  if (params.simulation_type == "Constant")
+    simulation_kind = 0;
+  else if (params.simulation_type == "Gaussian")
+    simulation_kind = 1;
+  else
+    throw std::runtime_error("SimulationType '" + params.simulation_type + "': not implemented");
   int level_number_type;
   if (params.mg_number_type == "double")
     level_number_type = MGAMD_F64;
@@ -334,7 +339,7 @@ run(const Context &ctx, const RunParameters &params, ConvergenceTable &table)
   Vector solution, rhs;
   op.initialize_dof_vector(solution);
   op.initialize_dof_vector(rhs);
-  op.rhs(rhs);
+  op.rhs(rhs, simulation_kind);
 
   table.add_value("dim", 3);
   table.add_value("n_cells", tria->n_global_active_cells());

@@ -98,6 +98,11 @@ int mgamd_dofs_get_keys(const mgamd_dofs *d, int32_t *keys);
 int mgamd_dofs_get_cell_dofs(const mgamd_dofs *d, uint32_t *out);
 /* Operator::rhs for f == 1, g == 0 (ref:include/operator.h:362-447, ref:multigrid_throughput.cc:2286-2291) */
 int mgamd_dofs_rhs_constant(const mgamd_dofs *d, double *out);
+/* Operator::rhs for SimulationType `kind` (0 "Constant": f = 1, g = 0; 1 "Gaussian": source and boundary values of
+ * ref:multigrid_throughput.cc:60-125,2294-2298): QGauss(p+1) load vector minus the Dirichlet lifting, constrained rows 0
+ * (ref:include/operator.h:362-447); and AffineConstraints::distribute on a host vector of n_dofs values */
+int mgamd_dofs_rhs(const mgamd_dofs *d, int kind, double *out);
+int mgamd_dofs_distribute(const mgamd_dofs *d, int kind, double *x);
 
 /* Domain decomposition (the reference partitions with p4est + RepartitioningPolicyTools,
  * ref:multigrid_throughput.cc:2066-2175).  trias: the level meshes, coarsest first.  A root level is chosen; its leaves are
@@ -187,6 +192,9 @@ int mgamd_level_op_vmult(mgamd_level_op *op, mgamd_vec *dst, const mgamd_vec *sr
 int mgamd_level_op_inverse_diagonal(mgamd_level_op *op, mgamd_vec *diagonal);
 /* Operator::rhs with f == 1, g == 0 (ref:include/operator.h:362-447) */
 int mgamd_level_op_rhs(mgamd_level_op *op, mgamd_vec *rhs);
+/* the same for SimulationType `kind` (see mgamd_dofs_rhs), and constraints.distribute(solution) after the solve */
+int mgamd_level_op_rhs_kind(mgamd_level_op *op, int kind, mgamd_vec *rhs);
+int mgamd_level_op_distribute(mgamd_level_op *op, int kind, mgamd_vec *x);
 
 /* development aid: with MGAMD_STAMPS=<mode> in the environment the largest slot group's kernel of that mode
  * records 8 wall-clock stamps (10 ns ticks) per workgroup at its phase boundaries; returns them */

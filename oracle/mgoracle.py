@@ -385,6 +385,7 @@ class Level:
         self.constrained = self.dirichlet | self.hanging
         free_or_dir = ~self.hanging
         Ch = sp.coo_matrix((vals, (rows, cols)), shape=(self.n, self.n)).tocsr() + sp.diags(free_or_dir.astype(float))
+        self.Ch = Ch  # hanging-node constraints only (Dirichlet DoFs kept): nodal values = Ch @ dof values
         # Dirichlet (homogeneous) columns vanish
         self.C = (Ch @ sp.diags((~self.dirichlet).astype(float))).tocsr()
 
@@ -410,6 +411,63 @@ class Level:
 
     def vmult(self, x):
         return self.A @ x
+
+    # -- general data (SimulationType "Gaussian", ref:multigrid_throughput.cc:60-125,2294-2298)
+    def node_positions(self):
+        """support point of every node/DoF (own nodes), shape (n, 3)"""
+        pos = np.zeros((self.n, 3))
+        n1, nodes = self.p + 1, self.fe.nodes
+        for ci, (l, i, j, k) in enumerate(self.cells):
+            h = 2.0 / (1 << l)
+            t = 0
+            for c in range(n1):
+                for b in range(n1):
+                    for a in range(n1):
+                        pos[self.cell_dofs[ci, t]] = (-1 + h * (i + nodes[a]), -1 + h * (j + nodes[b]), -1 + h * (k + nodes[c]))
+                        t += 1
+        return pos
+
+    def rhs_function(self, f, g):
+        """Operator::rhs (ref:include/operator.h:362-447): QGauss(p+1) load vector of f, minus the stiffness matrix without
+        Dirichlet constraints applied to the boundary interpolant of g (hanging nodes interpolated); constrained rows 0."""
+        fe, p, n1 = self.fe, self.p, self.p + 1
+        S = fe.S.reshape(n1, n1)  # [q, a]
+        F = np.zeros(self.n)
+        for ci, (l, i, j, k) in enumerate(self.cells):
+            h = 2.0 / (1 << l)
+            X = -1 + h * (i + fe.xq)[None, None, :] + 0 * fe.xq[:, None, None] + 0 * fe.xq[None, :, None]
+            Y = -1 + h * (j + fe.xq)[None, :, None] + 0 * X
+            Z = -1 + h * (k + fe.xq)[:, None, None] + 0 * X
+            W = h ** 3 * fe.wq[:, None, None] * fe.wq[None, :, None] * fe.wq[None, None, :]
+            fq = f(X, Y, Z) * W  # [qz, qy, qx]
+            loc = np.einsum("zyx,zc,yb,xa->cba", fq, S, S, S)
+            np.add.at(F, self.cell_dofs[ci], loc.ravel())
+        xg = np.zeros(self.n)
+        bd = self.dirichlet & ~self.hanging
+        pos = self.node_positions()
+        xg[bd] = g(pos[bd, 0], pos[bd, 1], pos[bd, 2])
+        b = self.Ch.T @ (F - self.Kraw @ (self.Ch @ xg))
+        b[self.constrained] = 0.0
+        return b
+
+    def distribute(self, x, g):
+        """AffineConstraints::distribute: Dirichlet values, then hanging nodes from their parents"""
+        x = x.copy()
+        bd = self.dirichlet & ~self.hanging
+        pos = self.node_positions()
+        x[bd] = g(pos[bd, 0], pos[bd, 1], pos[bd, 2])
+        x[self.hanging] = 0.0
+        return self.Ch @ x
+
+
+def gaussian_solution(x, y, z, width=0.1, centre=(-0.5, -0.5, -0.5)):
+    r2 = (x - centre[0]) ** 2 + (y - centre[1]) ** 2 + (z - centre[2]) ** 2
+    return np.exp(-r2 / width ** 2) / (np.sqrt(2 * np.pi) * width) ** 3
+
+
+def gaussian_rhs(x, y, z, width=0.1, centre=(-0.5, -0.5, -0.5)):
+    r2 = (x - centre[0]) ** 2 + (y - centre[1]) ** 2 + (z - centre[2]) ** 2
+    return (2 * 3 - 4 * r2 / width ** 2) / width ** 2 * np.exp(-r2 / width ** 2) / (np.sqrt(2 * np.pi) * width) ** 3
 
 
 # ----------------------------------------------------------------------------

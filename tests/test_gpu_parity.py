@@ -274,3 +274,22 @@ def test_collapsed_coarse_levels_same_vcycle(mgamd, ctx, geo, L, p, monkeypatch)
     ha.mg.vmult(za, mgamd.Vector(ctx, n).from_host(r))
     hb.mg.vmult(zb, mgamd.Vector(ctx, n).from_host(r))
     assert rel_err(za.to_host(), zb.to_host()) < 1e-12
+
+
+@pytest.mark.parametrize("geo,L,p,mg_type", [("quadrant", 3, 1, "HMG-global"), ("quadrant", 3, 4, "HMG-global"), ("annulus", 5, 2, "HMG-global")])
+def test_gaussian_simulation_type_solve(mgamd, oracle, ctx, hierarchies, geo, L, p, mg_type):
+    """SimulationType "Gaussian": right-hand side with Dirichlet lifting on the device path, the preconditioned solve
+    against the oracle's, and constraints.distribute of the solution (boundary values + hanging nodes)."""
+    h, levels, P = hierarchies(geo, L, p, mg_type)
+    mg = oracle.Multigrid(levels, P, 3, coarse="direct")
+    Lf = levels[-1]
+    bref = Lf.rhs_function(oracle.gaussian_rhs, oracle.gaussian_solution)
+    xref, itref, hist = oracle.pcg(Lf.A, bref, mg.vcycle, 1e-4)
+    b, x = h.fine_operator.initialize_dof_vector(), h.fine_operator.initialize_dof_vector()
+    h.fine_operator.rhs(b, 1)
+    assert rel_err(b.to_host(), bref) < 1e-12
+    it, res = mgamd.solve_cg(h.fine_operator, h.mg, x, b, 1e-4)
+    assert it == itref
+    assert rel_err(x.to_host(), xref) < TOL_SOL
+    h.fine_operator.distribute(x, 1)
+    assert rel_err(x.to_host(), Lf.distribute(xref, oracle.gaussian_solution)) < 10 * TOL_SOL

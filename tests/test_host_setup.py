@@ -183,3 +183,26 @@ def test_slot_decomposition_covers_every_cell_once(mgamd, geo, L, p, monkeypatch
     if p >= 2 and t.n_cells_hn > 0:
         assert dict(d.groups())[1] <= dict(d0.groups())[1]  # families absorb single cells
         assert d.info.n_interior >= d0.info.n_interior
+
+
+@pytest.mark.parametrize("geo,L,p", [("quadrant", 3, 1), ("quadrant", 3, 2), ("quadrant", 3, 4), ("annulus", 5, 2), ("hypercube", 2, 3), ("circle", 4, 3)])
+def test_gaussian_right_hand_side_and_distribute(mgamd, oracle, geo, L, p):
+    """SimulationType "Gaussian" (ref:multigrid_throughput.cc:60-125,2294-2298): quadrature load vector of f minus the
+    Dirichlet lifting of g (ref:include/operator.h:362-447), and constraints.distribute, against the textbook oracle
+    (assembled K, explicit hanging-node matrix)."""
+    t = mgamd.Triangulation(geo, L)
+    d = mgamd.DoFs(t, p, 0)
+    lv = oracle_level(oracle, d, geo, L, p)
+    ref = lv.rhs_function(oracle.gaussian_rhs, oracle.gaussian_solution)
+    got = d.rhs_function(1)
+    assert np.abs(got - ref).max() <= 1e-12 * max(np.abs(ref).max(), 1e-300)
+    assert np.array_equal(d.rhs_function(0), d.rhs_constant())
+    x = np.random.default_rng(2).standard_normal(d.n_dofs)
+    first_c = d.info.n_interior + d.info.n_tail
+    x[first_c:] = 0.0
+    xd, xr = d.distribute(x, 1), lv.distribute(x, oracle.gaussian_solution)
+    assert np.abs(xd - xr).max() <= 1e-13 * np.abs(xr).max()
+    assert np.array_equal(xd[:first_c], x[:first_c])
+    # homogeneous data: only the hanging nodes move
+    x0 = d.distribute(x, 0)
+    assert np.abs(x0 - lv.distribute(x, lambda a, b, c: 0 * a)).max() <= 1e-13 * np.abs(x).max()
