@@ -1543,6 +1543,176 @@ namespace mgamd
   }
 
   // ------------------------------------------------------------------------------------------
+  // p = 1 h-patches (coarse cell -> its 8 children, 3^3 fine nodes) in registers: one patch per thread, 256 consecutive
+  // patches per workgroup.  The coarse nodes of the workgroup's patches are deduplicated through LDS like the cell
+  // clusters of K1c: one load (prolongation) or one global atomic (restriction) per distinct coarse node instead of
+  // 8 per patch.  Index tables are stored transposed ([node][patch]) so that the threads of a wave read them coalesced.
+  // ------------------------------------------------------------------------------------------
+  template <typename T>
+  struct PatchP1Args
+  {
+    const uint32_t *uniq_ptr;    // [n_workgroups + 1] into uniq_idx
+    const uint32_t *uniq_idx;    // distinct coarse DoFs of a workgroup's patches
+    const uint16_t *loc;         // [n_patches * 8] workgroup-local id of coarse node x + 2y + 4z; 0xFFFF = Dirichlet
+    const uint16_t *coarse_mask; // [n_patches] hanging-node configuration of the coarse cell
+    const uint32_t *fine_idx_t;  // [27][n_patches] owned fine DoF of fine node X + 3Y + 9Z, INVALID otherwise
+    uint32_t        n_patches, max_uniq;
+    Mats<1>         m; // only I0/I1 are used
+    const T        *src;
+    T              *dst;
+  };
+  constexpr int PATCH_P1_BLOCK = 256;
+  constexpr int PATCH_P1_ITERS = 8;
+
+  template <typename T>
+  __global__ void
+  __launch_bounds__(PATCH_P1_BLOCK) patch_p1_prolongate_kernel(const PatchP1Args<T> a)
+  {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    T             *U    = reinterpret_cast<T *>(smem_raw);
+    const int      tid  = threadIdx.x;
+    const uint32_t wg   = blockIdx.x;
+    const uint32_t pch  = wg * PATCH_P1_BLOCK + tid;
+    const bool     act  = pch < a.n_patches;
+    const uint32_t p0   = a.uniq_ptr[wg];
+    const int      nu   = (int)(a.uniq_ptr[wg + 1] - p0);
+    const uint4    lw   = reinterpret_cast<const uint4 *>(a.loc)[act ? pch : 0];
+    const uint32_t mask = act ? a.coarse_mask[pch] : 0u;
+    uint32_t       fi[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t)
+      fi[t] = act ? a.fine_idx_t[(size_t)t * a.n_patches + pch] : DEV_INVALID;
+    T gv[PATCH_P1_ITERS];
+#pragma unroll
+    for (int k = 0; k < PATCH_P1_ITERS; ++k)
+      {
+        const int j = tid + k * PATCH_P1_BLOCK;
+        gv[k]       = nu > 0 ? a.src[a.uniq_idx[p0 + (j < nu ? j : nu - 1)]] : T(0);
+      }
+#pragma unroll
+    for (int k = 0; k < PATCH_P1_ITERS; ++k)
+      {
+        const int j = tid + k * PATCH_P1_BLOCK;
+        if (j < nu)
+          U[j] = gv[k];
+      }
+    __syncthreads();
+    const uint32_t lw4[4] = {lw.x, lw.y, lw.z, lw.w};
+    T              c[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      {
+        const uint32_t l = (lw4[i / 2] >> (16 * (i % 2))) & 0xFFFFu;
+        c[i]             = (act && l != 0xFFFFu) ? U[l] : T(0);
+      }
+    if (mask >> 3)
+      hanging_in_registers_p1<T, false>(c, mask, a.m);
+    // embedding 2 -> 3 nodes per direction: (c0, (c0 + c1)/2, c1)
+    T gx[12], gy[18];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      { // x: rows (y, z)
+        gx[3 * q + 0] = c[2 * q];
+        gx[3 * q + 1] = T(0.5) * (c[2 * q] + c[2 * q + 1]);
+        gx[3 * q + 2] = c[2 * q + 1];
+      }
+#pragma unroll
+    for (int z = 0; z < 2; ++z)
+#pragma unroll
+      for (int X = 0; X < 3; ++X)
+        { // y: gx index X + 3 (y + 2 z)
+          const T y0 = gx[X + 3 * (0 + 2 * z)], y1 = gx[X + 3 * (1 + 2 * z)];
+          gy[X + 3 * (0 + 3 * z)] = y0;
+          gy[X + 3 * (1 + 3 * z)] = T(0.5) * (y0 + y1);
+          gy[X + 3 * (2 + 3 * z)] = y1;
+        }
+    T oldv[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t)
+      oldv[t] = a.dst[fi[t] != DEV_INVALID ? fi[t] : 0];
+#pragma unroll
+    for (int XY = 0; XY < 9; ++XY)
+      { // z
+        const T z0 = gy[XY], z1 = gy[XY + 9];
+        const T f[3] = {z0, T(0.5) * (z0 + z1), z1};
+#pragma unroll
+        for (int Z = 0; Z < 3; ++Z)
+          if (fi[XY + 9 * Z] != DEV_INVALID)
+            a.dst[fi[XY + 9 * Z]] = oldv[XY + 9 * Z] + f[Z];
+      }
+  }
+
+  template <typename T>
+  __global__ void
+  __launch_bounds__(PATCH_P1_BLOCK) patch_p1_restrict_kernel(const PatchP1Args<T> a)
+  {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    T             *Acc  = reinterpret_cast<T *>(smem_raw);
+    const int      tid  = threadIdx.x;
+    const uint32_t wg   = blockIdx.x;
+    const uint32_t pch  = wg * PATCH_P1_BLOCK + tid;
+    const bool     act  = pch < a.n_patches;
+    const uint32_t p0   = a.uniq_ptr[wg];
+    const int      nu   = (int)(a.uniq_ptr[wg + 1] - p0);
+    const uint4    lw   = reinterpret_cast<const uint4 *>(a.loc)[act ? pch : 0];
+    const uint32_t mask = act ? a.coarse_mask[pch] : 0u;
+    uint32_t       fi[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t)
+      fi[t] = act ? a.fine_idx_t[(size_t)t * a.n_patches + pch] : DEV_INVALID;
+    T r[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t)
+      r[t] = a.src[fi[t] != DEV_INVALID ? fi[t] : 0];
+#pragma unroll
+    for (int t = 0; t < 27; ++t)
+      if (fi[t] == DEV_INVALID)
+        r[t] = T(0);
+    for (int j = tid; j < nu; j += PATCH_P1_BLOCK)
+      Acc[j] = T(0);
+    // transpose of the embedding, z then y then x: (f0 + f1/2, f1/2 + f2)
+    T gy[18], gx[12], c[8];
+#pragma unroll
+    for (int XY = 0; XY < 9; ++XY)
+      {
+        gy[XY]     = r[XY] + T(0.5) * r[XY + 9];
+        gy[XY + 9] = T(0.5) * r[XY + 9] + r[XY + 18];
+      }
+#pragma unroll
+    for (int z = 0; z < 2; ++z)
+#pragma unroll
+      for (int X = 0; X < 3; ++X)
+        {
+          const T y0 = gy[X + 3 * (0 + 3 * z)], y1 = gy[X + 3 * (1 + 3 * z)], y2 = gy[X + 3 * (2 + 3 * z)];
+          gx[X + 3 * (0 + 2 * z)] = y0 + T(0.5) * y1;
+          gx[X + 3 * (1 + 2 * z)] = T(0.5) * y1 + y2;
+        }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      {
+        c[2 * q]     = gx[3 * q] + T(0.5) * gx[3 * q + 1];
+        c[2 * q + 1] = T(0.5) * gx[3 * q + 1] + gx[3 * q + 2];
+      }
+    if (mask >> 3)
+      hanging_in_registers_p1<T, true>(c, mask, a.m);
+    __syncthreads();
+    const uint32_t lw4[4] = {lw.x, lw.y, lw.z, lw.w};
+    if (act)
+      {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          {
+            const uint32_t l = (lw4[i / 2] >> (16 * (i % 2))) & 0xFFFFu;
+            if (l != 0xFFFFu)
+              atomic_add(&Acc[l], c[i]);
+          }
+      }
+    __syncthreads();
+    for (int j = tid; j < nu; j += PATCH_P1_BLOCK)
+      atomic_add(&a.dst[a.uniq_idx[p0 + j]], Acc[j]);
+  }
+
+  // ------------------------------------------------------------------------------------------
   // Brick-level h-transfer: one fine brick (lattice NF = P*B+1) <-> the (B/2)^3 coarse cells under it
   // (lattice NC = P*B/2+1).  Interior fine DoFs are contiguous (coalesced read-modify-write); the shell
   // uses the brick's ownership list.  Restriction adds to the coarse vector with plain read-modify-write

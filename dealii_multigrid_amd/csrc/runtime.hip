@@ -978,6 +978,48 @@ namespace mgamd
       DBuf<uint32_t>      coarse_idx, fine_idx, fine_idx_restrict; // restrict list: copies of other ranks' DoFs removed
       DBuf<uint16_t>      coarse_mask;
       std::vector<double> E;
+      // p = 1 h-patches: tables of the register kernels (patch_p1_*_kernel)
+      DBuf<uint32_t> p1_uniq_ptr, p1_uniq_idx, p1_fine_t, p1_fine_t_restrict;
+      DBuf<uint16_t> p1_loc;
+      uint32_t       p1_max_uniq = 0;
+      void
+      build_p1(const std::vector<uint32_t> &cidx, const std::vector<uint32_t> &fidx, const std::vector<uint32_t> *fidx_restrict)
+      {
+        const size_t          np = n_patches, nwg = (np + PATCH_P1_BLOCK - 1) / PATCH_P1_BLOCK;
+        std::vector<uint32_t> ptr(nwg + 1, 0), idx, tmp;
+        std::vector<uint16_t> l(np * 8, 0xFFFFu);
+        for (size_t w = 0; w < nwg; ++w)
+          {
+            const size_t a = w * PATCH_P1_BLOCK, b = std::min(np, a + PATCH_P1_BLOCK);
+            tmp.clear();
+            for (size_t i = a * 8; i < b * 8; ++i)
+              if (cidx[i] != INVALID_DOF)
+                tmp.push_back(cidx[i]);
+            std::sort(tmp.begin(), tmp.end());
+            tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+            for (size_t i = a * 8; i < b * 8; ++i)
+              if (cidx[i] != INVALID_DOF)
+                l[i] = (uint16_t)(std::lower_bound(tmp.begin(), tmp.end(), cidx[i]) - tmp.begin());
+            idx.insert(idx.end(), tmp.begin(), tmp.end());
+            ptr[w + 1]  = (uint32_t)idx.size();
+            p1_max_uniq = std::max<uint32_t>(p1_max_uniq, (uint32_t)tmp.size());
+          }
+        if (idx.empty())
+          idx.push_back(0);
+        auto transpose = [&](const std::vector<uint32_t> &f) {
+          std::vector<uint32_t> t(f.size());
+          for (size_t q = 0; q < np; ++q)
+            for (int k = 0; k < 27; ++k)
+              t[(size_t)k * np + q] = f[q * 27 + k];
+          return t;
+        };
+        p1_uniq_ptr.upload(ptr);
+        p1_uniq_idx.upload(idx);
+        p1_loc.upload(l);
+        p1_fine_t.upload(transpose(fidx));
+        if (fidx_restrict)
+          p1_fine_t_restrict.upload(transpose(*fidx_restrict));
+      }
     };
     struct BrickD
     {
@@ -1037,6 +1079,16 @@ namespace mgamd
               grp[k].fine_idx.upload(tt.groups[k].fine_idx);
               if (copy_hi > copy_lo)
                 grp[k].fine_idx_restrict.upload(owned_only(tt.groups[k].fine_idx));
+              if (k == 1 && tt.pc == 1 && grp[k].nf == 3 && !getenv("MGAMD_NO_P1_PATCH_KERNELS"))
+                {
+                  if (copy_hi > copy_lo)
+                    {
+                      const std::vector<uint32_t> fr = owned_only(tt.groups[k].fine_idx);
+                      grp[k].build_p1(tt.groups[k].coarse_idx, tt.groups[k].fine_idx, &fr);
+                    }
+                  else
+                    grp[k].build_p1(tt.groups[k].coarse_idx, tt.groups[k].fine_idx, nullptr);
+                }
             }
           grp[k].E = fec.embedding(k, pf);
         }
@@ -1071,6 +1123,34 @@ namespace mgamd
         hipLaunchKernelGGL((prolongate_kernel<T, PC, NF, IDENTITY>), grid, G::BLOCK, lds, ctx->stream, a);
       else
         hipLaunchKernelGGL((restrict_kernel<T, PC, NF, IDENTITY>), grid, G::BLOCK, lds, ctx->stream, a);
+      HIP_CHECK(hipGetLastError());
+    }
+
+    void
+    launch_p1(const GroupD &g, const T *src, T *dst, bool prolongate)
+    {
+      PatchP1Args<T> a;
+      a.uniq_ptr    = g.p1_uniq_ptr.p;
+      a.uniq_idx    = g.p1_uniq_idx.p;
+      a.loc         = g.p1_loc.p;
+      a.coarse_mask = g.coarse_mask.p;
+      a.fine_idx_t  = (!prolongate && g.p1_fine_t_restrict.p) ? g.p1_fine_t_restrict.p : g.p1_fine_t.p;
+      a.n_patches   = (uint32_t)g.n_patches;
+      a.max_uniq    = g.p1_max_uniq;
+      for (int i = 0; i < 4; ++i)
+        {
+          a.m.M[i] = a.m.K[i] = 0.0;
+          a.m.I0[i]           = fec.I[0][i];
+          a.m.I1[i]           = fec.I[1][i];
+        }
+      a.src = src;
+      a.dst = dst;
+      const int    grid = (int)((g.n_patches + PATCH_P1_BLOCK - 1) / PATCH_P1_BLOCK);
+      const size_t lds  = (size_t)std::max<uint32_t>(g.p1_max_uniq, 1) * sizeof(T);
+      if (prolongate)
+        hipLaunchKernelGGL(patch_p1_prolongate_kernel<T>, grid, PATCH_P1_BLOCK, lds, ctx->stream, a);
+      else
+        hipLaunchKernelGGL(patch_p1_restrict_kernel<T>, grid, PATCH_P1_BLOCK, lds, ctx->stream, a);
       HIP_CHECK(hipGetLastError());
     }
 
@@ -1193,7 +1273,10 @@ namespace mgamd
             switch (key)
               {
                 case 103:
-                  launch<1, 3, false>(g, src, dst, prolongate);
+                  if (g.p1_uniq_ptr.p)
+                    launch_p1(g, src, dst, prolongate);
+                  else
+                    launch<1, 3, false>(g, src, dst, prolongate);
                   break;
                 case 104:
                   launch<1, 4, false>(g, src, dst, prolongate);
