@@ -1457,7 +1457,8 @@ namespace mgamd
           lc = l;
         else
           break;
-      if (lc == 0 || ops[0]->comm)
+      // an iterative coarse solver (cg, cg_with_chebyshev) is not a linear map of its right-hand side
+      if (lc == 0 || ops[0]->comm || coarse_type != "direct")
         return;
       const size_t        n = ops[lc]->n_dofs();
       std::vector<T>      col(n);
