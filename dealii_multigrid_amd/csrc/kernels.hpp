@@ -564,7 +564,7 @@ namespace mgamd
 #ifdef MGAMD_KERNEL_DEBUG
 #define MGAMD_STAMP(k)                         \
   if (args.stamps && tid == 0)                 \
-    args.stamps[(size_t)blockIdx.x * 8 + (k)] = wall_clock64();
+    args.stamps[(size_t)block * 8 + (k)] = wall_clock64();
 #define MGAMD_ABLATED(bit) (args.ablate & (bit))
 #else
 #define MGAMD_STAMP(k)
@@ -573,13 +573,13 @@ namespace mgamd
 
   // waves per SIMD: 2 for the 17^3 lattices (<= 256 VGPRs); 6 for single-cell slots (<= 80 VGPRs, measured 5 % faster at
   // p = 4 than unconstrained with 110 VGPRs)
+  // the work of workgroup `block` of `nblocks` on the slots of args.g (kernels below)
   template <typename T, int P, int B, int MODE>
-  __global__ void
-  __launch_bounds__((Geo<P, B>::ABLOCK), (Geo<P, B>::ROUNDS > 1 ? 2 : (B == 1 ? 6 : 1))) lattice_apply_kernel(const ApplyArgs<T, P> args)
+  __device__ __forceinline__ void
+  lattice_apply_body(const ApplyArgs<T, P> &args, const uint32_t block, const uint32_t nblocks, unsigned char *smem_raw)
   {
     using G  = Geo<P, B>;
     using IM = InteriorMap<P, B>;
-    extern __shared__ __align__(16) unsigned char smem_raw[];
     T *bufA = reinterpret_cast<T *>(smem_raw);
     T *bufB = bufA + G::SPW * G::N3;
 
@@ -588,7 +588,7 @@ namespace mgamd
     constexpr int ITERS = (G::SPW * G::N_SHELL + BLOCK - 1) / BLOCK;
 
     const int tid    = threadIdx.x;
-    const int slot0  = (int)xcd_contiguous(blockIdx.x, gridDim.x) * G::SPW;
+    const int slot0  = (int)xcd_contiguous(block, nblocks) * G::SPW;
     const int nslots = min((int)G::SPW, (int)args.g.n_slots - slot0);
     MGAMD_STAMP(0)
 
@@ -847,6 +847,40 @@ namespace mgamd
   }
 #undef MGAMD_STAMP
 #undef MGAMD_ABLATED
+
+  template <typename T, int P, int B, int MODE>
+  __global__ void
+  __launch_bounds__((Geo<P, B>::ABLOCK), (Geo<P, B>::ROUNDS > 1 ? 2 : (B == 1 ? 6 : 1))) lattice_apply_kernel(const ApplyArgs<T, P> args)
+  {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    lattice_apply_body<T, P, B, MODE>(args, blockIdx.x, gridDim.x, smem_raw);
+  }
+
+  // The 2^3 bricks and the single cells of a level in ONE launch (both have 256-thread workgroups and 20-35 KB of LDS):
+  // on levels where each of them is a fraction of one round of workgroups, a launch costs a workgroup lifetime whatever
+  // it does.  (Merging the 17^3 bricks in as well was measured slower: every workgroup then reserves their 78 KB.)
+  template <typename T, int P>
+  struct SmallSlotsArgs
+  {
+    ApplyArgs<T, P> a;       // a.g = the 2^3-brick group
+    SlotGroupDev    g_cells; // the single-cell group
+    uint32_t        n_wg_bricks;
+  };
+  template <typename T, int P, int MODE>
+  __global__ void
+  __launch_bounds__(256) lattice_apply_small_kernel(const SmallSlotsArgs<T, P> args)
+  {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    if (blockIdx.x < args.n_wg_bricks)
+      lattice_apply_body<T, P, 2, MODE>(args.a, blockIdx.x, args.n_wg_bricks, smem_raw);
+    else
+      {
+        ApplyArgs<T, P> a = args.a;
+        a.g               = args.g_cells;
+        a.stamps          = nullptr;
+        lattice_apply_body<T, P, 1, MODE>(a, blockIdx.x - args.n_wg_bricks, gridDim.x - args.n_wg_bricks, smem_raw);
+      }
+  }
 
   // K1c: the level operator on SINGLE CELLS at p = 1, one cell per thread, 256 consecutive (Morton) cells per
   // workgroup (a CLUSTER).  The generic kernel spends one scattered load and one global atomic per (cell, node):

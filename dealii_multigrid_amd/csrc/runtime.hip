@@ -361,6 +361,7 @@ namespace mgamd
     uint32_t                                  ablate = 0; // debug: MGAMD_ABLATE
     DBuf<unsigned long long>                  stamps;     // debug: MGAMD_STAMPS=<mode>, 8 stamps per workgroup of the largest group
     int                                       stamp_mode = -1;
+    bool                                      merge_small = true; // MGAMD_NO_MERGE_SMALL=1: separate launches (development A/B)
 
     // sharded runs: device image of the halo plan
     struct HaloDev
@@ -422,6 +423,7 @@ namespace mgamd
         }
       if (const char *e = getenv("MGAMD_ABLATE"))
         ablate = (uint32_t)atoi(e);
+      merge_small = getenv("MGAMD_NO_MERGE_SMALL") == nullptr;
       if (const char *e = getenv("MGAMD_STAMPS"))
         {
           stamp_mode = atoi(e);
@@ -550,10 +552,23 @@ namespace mgamd
       a.ablate     = ablate;
       a.stamps     = nullptr;
       a.epi        = epi;
+      // 2^3 bricks and single cells in one launch (lattice_apply_small_kernel) when both exist
+      GroupDev<T> *g2 = nullptr, *g1 = nullptr;
+      if (P >= 2 && !diag && merge_small)
+        for (auto &g : groups)
+          {
+            if (g->n_slots && g->B == 2)
+              g2 = g.get();
+            else if (g->n_slots && g->B == 1)
+              g1 = g.get();
+          }
+      const bool merged = g2 && g1;
       for (auto &g : groups)
         {
           if (!g->n_slots)
             continue;
+          if (merged && g.get() == g1)
+            continue; // done together with the 2^3 bricks
           a.g      = g->view();
           a.stamps = (stamps.p && g->B == prof_B && MODE == stamp_mode && !diag) ? stamps.p : nullptr;
           const bool prof = ctx->profile && !diag && MODE == MODE_CHEB && g->B == (ctx->prof_brick ? ctx->prof_brick : prof_B);
@@ -570,6 +585,22 @@ namespace mgamd
             }
           if (P == 1 && !diag && g->has_clusters())
             launch_clusters(*g, src, epi, MODE == MODE_CHEB_FIRST);
+          else if (merged && g.get() == g2)
+            {
+              if constexpr (P >= 2)
+                {
+                  using G2 = Geo<P, 2>;
+                  using G1 = Geo<P, 1>;
+                  SmallSlotsArgs<T, P> sa;
+                  sa.a           = a;
+                  sa.g_cells     = g1->view();
+                  sa.n_wg_bricks = (uint32_t)((g2->n_slots + G2::SPW - 1) / G2::SPW);
+                  const uint32_t n_wg_cells = (uint32_t)((g1->n_slots + G1::SPW - 1) / G1::SPW);
+                  const size_t   lds = (std::max(2 * (size_t)G2::SPW * G2::N3, 2 * (size_t)G1::SPW * G1::N3) + 2 * P * P * P + std::max(G2::SPW, G1::SPW)) * sizeof(T);
+                  hipLaunchKernelGGL((lattice_apply_small_kernel<T, P, MODE>), sa.n_wg_bricks + n_wg_cells, 256, lds, ctx->stream, sa);
+                  HIP_CHECK(hipGetLastError());
+                }
+            }
           else
             dispatch_B<T, P, MODE>(ctx, g->B, a, diag);
           if (prof)
