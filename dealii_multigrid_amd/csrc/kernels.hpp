@@ -974,15 +974,14 @@ namespace mgamd
   }
 
   template <typename T>
-  __global__ void
-  __launch_bounds__(CLUSTER_CELLS) cell_cluster_apply_kernel(const ClusterArgs<T> a)
+  __device__ __forceinline__ void
+  cell_cluster_body(const ClusterArgs<T> &a, const uint32_t block, const uint32_t nblocks, unsigned char *smem_raw)
   {
-    extern __shared__ __align__(16) unsigned char smem_raw[];
     T *U   = reinterpret_cast<T *>(smem_raw);
     T *Acc = U + a.c.max_uniq;
 
     const int      tid  = threadIdx.x;
-    const uint32_t cl   = xcd_contiguous(blockIdx.x, gridDim.x);
+    const uint32_t cl   = xcd_contiguous(block, nblocks);
     const uint32_t slot = cl * CLUSTER_CELLS + tid;
     const bool     act  = slot < a.c.n_slots;
     const uint32_t p0   = a.c.uniq_ptr[cl];
@@ -1091,6 +1090,33 @@ namespace mgamd
         if (j < nu)
           atomic_add(&a.tail_acc[gi[k] - a.n_interior], Acc[j]);
       }
+  }
+
+  template <typename T>
+  __global__ void
+  __launch_bounds__(CLUSTER_CELLS) cell_cluster_apply_kernel(const ClusterArgs<T> a)
+  {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    cell_cluster_body<T>(a, blockIdx.x, gridDim.x, smem_raw);
+  }
+
+  // p = 1: the 8^3 bricks and the cell clusters of a level in one launch (same reason as lattice_apply_small_kernel)
+  template <typename T>
+  struct P1SmallArgs
+  {
+    ApplyArgs<T, 1> a; // a.g = the 8^3-brick group
+    ClusterArgs<T>  c;
+    uint32_t        n_wg_bricks;
+  };
+  template <typename T, int MODE>
+  __global__ void
+  __launch_bounds__(256) lattice_cluster_kernel(const P1SmallArgs<T> args)
+  {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    if (blockIdx.x < args.n_wg_bricks)
+      lattice_apply_body<T, 1, 8, MODE>(args.a, blockIdx.x, args.n_wg_bricks, smem_raw);
+    else
+      cell_cluster_body<T>(args.c, blockIdx.x - args.n_wg_bricks, gridDim.x - args.n_wg_bricks, smem_raw);
   }
 
   // Diagonal of C^T K C.  Slots without hanging nodes: closed tensor form; single cells with hanging

@@ -522,6 +522,22 @@ namespace mgamd
       return m;
     }
 
+    ClusterArgs<T>
+    cluster_args(const GroupDev<T> &g, const T *src, const Epilogue<T> &epi, bool first)
+    {
+      ClusterArgs<T> a;
+      a.c          = g.cluster_view();
+      a.m          = mats<1>();
+      a.src        = src;
+      a.tail_acc   = tail_acc.p;
+      a.n_interior = tables->n_interior;
+      a.b          = epi.b;
+      a.dinv       = epi.dinv;
+      a.c0         = epi.c0;
+      a.from_b     = first ? 1 : 0;
+      return a;
+    }
+
     void
     launch_clusters(const GroupDev<T> &g, const T *src, const Epilogue<T> &epi, bool first)
     {
@@ -563,12 +579,23 @@ namespace mgamd
               g1 = g.get();
           }
       const bool merged = g2 && g1;
+      // p = 1: the 8^3 bricks together with the cell clusters (lattice_cluster_kernel)
+      GroupDev<T> *g8 = nullptr, *gc = nullptr;
+      if (P == 1 && !diag && merge_small)
+        for (auto &g : groups)
+          {
+            if (g->n_slots && g->B == 8 && g->B != prof_B)
+              g8 = g.get();
+            else if (g->n_slots && g->B == 1 && g->has_clusters())
+              gc = g.get();
+          }
+      const bool merged_p1 = g8 && gc;
       for (auto &g : groups)
         {
           if (!g->n_slots)
             continue;
-          if (merged && g.get() == g1)
-            continue; // done together with the 2^3 bricks
+          if ((merged && g.get() == g1) || (merged_p1 && g.get() == gc))
+            continue; // done together with the 2^3 (8^3) bricks
           a.g      = g->view();
           a.stamps = (stamps.p && g->B == prof_B && MODE == stamp_mode && !diag) ? stamps.p : nullptr;
           const bool prof = ctx->profile && !diag && MODE == MODE_CHEB && g->B == (ctx->prof_brick ? ctx->prof_brick : prof_B);
@@ -583,7 +610,23 @@ namespace mgamd
                 }
               HIP_CHECK(hipEventRecord(ctx->prof_events[ctx->prof_used].first, ctx->stream));
             }
-          if (P == 1 && !diag && g->has_clusters())
+          if (merged_p1 && g.get() == g8)
+            {
+              if constexpr (P == 1)
+                {
+                  using G8 = Geo<1, 8>;
+                  P1SmallArgs<T> sa;
+                  sa.a           = a;
+                  sa.c           = cluster_args(*gc, src, epi, MODE == MODE_CHEB_FIRST);
+                  sa.n_wg_bricks = (uint32_t)((g8->n_slots + G8::SPW - 1) / G8::SPW);
+                  const uint32_t n_wg_cl = (uint32_t)((gc->n_slots + CLUSTER_CELLS - 1) / CLUSTER_CELLS);
+                  const size_t   lds     = std::max((2 * (size_t)G8::SPW * G8::N3 + 2 + G8::SPW) * sizeof(T),
+                                              2 * (size_t)std::max<uint32_t>(gc->max_uniq, 1) * sizeof(T));
+                  hipLaunchKernelGGL((lattice_cluster_kernel<T, MODE>), sa.n_wg_bricks + n_wg_cl, 256, lds, ctx->stream, sa);
+                  HIP_CHECK(hipGetLastError());
+                }
+            }
+          else if (P == 1 && !diag && g->has_clusters())
             launch_clusters(*g, src, epi, MODE == MODE_CHEB_FIRST);
           else if (merged && g.get() == g2)
             {
