@@ -29,6 +29,7 @@ def run_instance(out, counter, geometry_type, n_refinements, k, solver, partitio
         datastore["PartitionerName"] = partitioner
     if overrides:
         datastore.update(overrides)
+    os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, "input_%s.json" % str(counter).zfill(4)), "w") as f:
         json.dump(datastore, f, indent=4, separators=(",", ": "))
 
