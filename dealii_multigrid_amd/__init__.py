@@ -534,12 +534,13 @@ class DistributedHierarchy:
 
     def __init__(self, ctx: Context, comm: Communicator, geometry="quadrant", n_ref_global=3, degree=1, smoother_degree=3,
                  smoothing_range=20.0, eig_cg_n_iterations=20, coarse_solver="amg", number_type=F64, hanging_weight=2.0, max_brick=-1,
-                 min_root_dofs=1_000_000):
+                 min_root_dofs=4_000_000):
         self.ctx, self.comm = ctx, comm
         fine = Triangulation(geometry, n_ref_global)
         self.trias = create_geometric_coarsening_sequence(fine)
-        # levels below ~1 M DoFs stay replicated: their single-GPU time (latency-bound, <= 0.3 ms) is below what the
-        # halo exchanges of a distributed level cost
+        # levels below ~4 M DoFs stay replicated: their single-GPU time (latency-bound: 0.34 ms for 2.3 M DoFs at p=4,
+        # 0.33 ms for 2.2 M at p=1) is below what a distributed level pays for its 8 halo exchanges per cycle on top of its
+        # own (also latency-bound) kernels
         self.partition = Partition(self.trias, comm.n_ranks, hanging_weight, min_root_dofs // degree ** 3)
         nl = len(self.trias)
         self.dofs = [DoFs(self.trias[l], degree, max_brick, self.partition, l, comm.rank) for l in range(nl)]
