@@ -38,3 +38,8 @@ clean:
 	rm -rf $(LIBDIR)/*.o $(LIB) oracle/_build
 
 .PHONY: all oracle clean
+
+# development build with in-kernel stamps / ablations (tools/stamps.py): MGAMD_LIBRARY=dealii_multigrid_amd/lib_debug/libmgamd.so
+debug:
+	$(MAKE) LIBDIR=dealii_multigrid_amd/lib_debug DEBUGFLAGS=-DMGAMD_KERNEL_DEBUG dealii_multigrid_amd/lib_debug/libmgamd.so
+.PHONY: debug

@@ -21,7 +21,8 @@ import os
 
 import numpy as np
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmgamd.so")
+# MGAMD_LIBRARY: another build of the same library (development: the -DMGAMD_KERNEL_DEBUG build of `make debug`)
+_LIB_PATH = os.environ.get("MGAMD_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmgamd.so")
 F64, F32 = 8, 4
 INVALID_DOF = 0xFFFFFFFF
 
@@ -192,6 +193,18 @@ class DoFs:
 
     def groups(self):
         return [(self.info.group_B[g], self.info.group_slots[g]) for g in range(self.info.n_groups)]
+
+    def pipeline(self):
+        """(group, chunk_slot_end, tail_stage_end) of the pipelined operator pass; group = -1: not pipelined"""
+        g, n = C.c_int(), C.c_uint32()
+        ce, te = (C.c_uint32 * 16)(), (C.c_uint32 * 16)()
+        _chk(_lib.mgamd_dofs_pipeline(self._h, C.byref(g), C.byref(n), ce, te))
+        return g.value, list(ce[: n.value]), list(te[: n.value])
+
+    def cell_slots(self):
+        grp, slot = np.zeros(self.info.n_cells, np.uint8), np.zeros(self.info.n_cells, np.uint32)
+        _chk(_lib.mgamd_dofs_get_cell_slots(self._h, _ptr(grp), _ptr(slot)))
+        return grp, slot
 
     def halo_plan(self):
         """host copy of the halo plan of a distributed level (see mgamd_dofs_halo_get)."""
@@ -475,6 +488,18 @@ class PreconditionMG:
             return
         self._cb = _STAGE_CB(lambda s, st, lv, u: fn(s, bool(st), lv))
         _chk(_lib.mgamd_mg_set_stage_callback(self._h, self._cb, None))
+
+    def stage_timing(self, enable: bool):
+        """HIP-event stage timing of the unchanged cycle (no host synchronisation inside the cycle)"""
+        _chk(_lib.mgamd_mg_stage_timing(self._h, 1 if enable else 0))
+
+    def stage_times(self):
+        """milliseconds accumulated per [stage, level] since the last call (see STAGE_NAMES)"""
+        n = len(self.levels)
+        ms = np.zeros((9, n))
+        cnt = C.c_uint64()
+        _chk(_lib.mgamd_mg_stage_times(self._h, _ptr(ms), n, C.byref(cnt)))
+        return ms
 
     def time_vcycles(self, z: Vector, r: Vector, n: int, use_graph: bool = True) -> float:
         ms = C.c_double()

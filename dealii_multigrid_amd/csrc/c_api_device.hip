@@ -551,6 +551,30 @@ mgamd_mg_set_stage_callback(mgamd_mg *mg, mgamd_stage_callback cb, void *user)
 }
 
 int
+mgamd_mg_stage_timing(mgamd_mg *mg, int enable)
+{
+  MGAMD_TRY
+  if (!mg)
+    throw std::invalid_argument("null argument");
+  mg->mg->set_stage_timing(enable != 0);
+  MGAMD_CATCH
+}
+
+int
+mgamd_mg_stage_times(mgamd_mg *mg, double *ms, unsigned n_levels, uint64_t *n_records)
+{
+  MGAMD_TRY
+  if (!mg || !ms)
+    throw std::invalid_argument("null argument");
+  if (n_levels != mg->mg->n_levels())
+    throw std::invalid_argument("stage_times: ms must hold 9 x n_levels entries");
+  const size_t n = mg->mg->read_stage_times(ms);
+  if (n_records)
+    *n_records = n;
+  MGAMD_CATCH
+}
+
+int
 mgamd_mg_time_vcycles(mgamd_mg *mg, mgamd_vec *z, const mgamd_vec *r, unsigned n, int use_graph, double *ms_per_cycle)
 {
   MGAMD_TRY

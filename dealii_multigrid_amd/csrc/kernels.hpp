@@ -297,6 +297,66 @@ namespace mgamd
       }
   }
 
+  // ---- SEGMENT tasks for the 17-point lattices.  17^2 = 289 lines do not fit one round of 256 threads, and a second round
+  // of whole lines runs with 33 of 256 lanes (measured: the sweeps are 5.9 of the 13-16 us a workgroup lives).  The 33
+  // left-over lines are cut into 4 segments of 5 nodes (4 s .. 4 s + 4: one cell at p = 4, two at p = 2, four at p = 1):
+  // 132 tasks of a quarter line each.  A task owns the nodes 4 s .. 4 s + 3 (and node 16 for s = 3): it also adds the
+  // contribution of the cell to its left to node 4 s, for which it reads that cell's other P nodes.  The four tasks of a
+  // line sit in adjacent lanes of ONE wavefront and update the line in place: every lane has read its inputs before any
+  // lane writes (lock step, LDS operations of a wave complete in order; seg_fence() keeps the compiler from sinking a
+  // load below the stores).
+  __device__ __forceinline__ void
+  seg_fence()
+  {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  // KIND 0: o1 = M a, o2 = K a;  1: o1 = M a, o2 = K a + M b;  2: o2 = K a + M b.   a, b: [P left nodes | 5 own nodes]
+  template <typename T, int P, int KIND>
+  __device__ __forceinline__ void
+  seg_products(const Mats<P> &m, const T (&a)[P + 5], const T (&b)[P + 5], const bool has_left, T (&o1)[5], T (&o2)[5])
+  {
+    static_assert(4 % P == 0, "segments of 5 nodes need P in {1, 2, 4}");
+    constexpr int CPS = 4 / P; // cells per segment
+    T             oa[5], ob[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+      {
+        oa[i] = a[P + i];
+        ob[i] = b[P + i];
+      }
+    if constexpr (KIND == 0)
+      line_MK<T, P, CPS>(m, oa, o1, o2);
+    else if constexpr (KIND == 1)
+      line_M_KM<T, P, CPS>(m, oa, ob, o1, o2);
+    else
+      line_KM<T, P, CPS>(m, oa, ob, o2);
+    // left cell [4 s - P, 4 s]: its last row acts on node 4 s
+    T l1 = T(0), l2 = T(0);
+#pragma unroll
+    for (int j = 0; j <= P; ++j)
+      {
+        const T Mj = T(m.M[P * (P + 1) + j]), Kj = T(m.K[P * (P + 1) + j]);
+        if constexpr (KIND == 0)
+          {
+            l1 += Mj * a[j];
+            l2 += Kj * a[j];
+          }
+        else if constexpr (KIND == 1)
+          {
+            l1 += Mj * a[j];
+            l2 += Kj * a[j] + Mj * b[j];
+          }
+        else
+          l2 += Kj * a[j] + Mj * b[j];
+      }
+    if (has_left)
+      {
+        if constexpr (KIND != 2)
+          o1[0] += l1;
+        o2[0] += l2;
+      }
+  }
+
   // The three sweeps.  Line l = tid + r*BLOCK (r < ROUNDS) of the workgroup is (slot sl, u, v) in every sweep.
   // bufA holds the input and receives the result; bufB is scratch.  Ends with a barrier.
   template <typename T, int P, int B, int BLOCK>
@@ -307,8 +367,14 @@ namespace mgamd
     constexpr int N      = G::N;
     constexpr int N3     = G::N3;
     constexpr int TOT    = G::SPW * G::LINES;
-    constexpr int ROUNDS = (TOT + BLOCK - 1) / BLOCK;
-    T             r0[N], r1[N], r2[N];
+    // 17-point lattices: one round of whole lines + segment tasks for the rest
+    constexpr bool SEGMENTS = N == 17 && G::SPW == 1 && TOT > BLOCK && 4 * (TOT - BLOCK) <= BLOCK && (4 % P == 0);
+    constexpr int  ROUNDS   = SEGMENTS ? 1 : (TOT + BLOCK - 1) / BLOCK;
+    constexpr int  NSEG     = SEGMENTS ? 4 * (TOT - BLOCK) : 0;
+    // segment task of this thread: line BLOCK + tid / 4, segment tid % 4
+    const int  sg_l = BLOCK + (tid >> 2), sg_s = tid & 3, sg_u = sg_l % N, sg_v = sg_l / N;
+    const bool sg   = SEGMENTS && tid < NSEG;
+    T          r0[N], r1[N], r2[N];
     // z sweep: line = (x=u, y=v)
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r)
@@ -329,6 +395,24 @@ namespace mgamd
               }
           }
       }
+    if constexpr (SEGMENTS)
+      if (sg)
+        {
+          const int base = sg_v * N + sg_u + 4 * sg_s * N * N;
+          T         a[P + 5], o1[5], o2[5];
+#pragma unroll
+          for (int i = 0; i < P + 5; ++i)
+            a[i] = (sg_s > 0 || i >= P) ? bufA[base + (i - P) * N * N] : T(0);
+          seg_fence();
+          seg_products<T, P, 0>(m, a, a, sg_s > 0, o1, o2);
+#pragma unroll
+          for (int i = 0; i < 5; ++i)
+            if (i < 4 || sg_s == 3)
+              {
+                bufA[base + i * N * N] = o1[i];
+                bufB[base + i * N * N] = o2[i];
+              }
+        }
     __syncthreads();
     // y sweep: line = (x=u, z=v):  c = My a ; g = Ky a + My b
 #pragma unroll
@@ -354,6 +438,27 @@ namespace mgamd
               }
           }
       }
+    if constexpr (SEGMENTS)
+      if (sg)
+        {
+          const int base = sg_v * N * N + sg_u + 4 * sg_s * N;
+          T         a[P + 5], b[P + 5], o1[5], o2[5];
+#pragma unroll
+          for (int i = 0; i < P + 5; ++i)
+            {
+              a[i] = (sg_s > 0 || i >= P) ? bufA[base + (i - P) * N] : T(0);
+              b[i] = (sg_s > 0 || i >= P) ? bufB[base + (i - P) * N] : T(0);
+            }
+          seg_fence();
+          seg_products<T, P, 1>(m, a, b, sg_s > 0, o1, o2);
+#pragma unroll
+          for (int i = 0; i < 5; ++i)
+            if (i < 4 || sg_s == 3)
+              {
+                bufA[base + i * N] = o1[i];
+                bufB[base + i * N] = o2[i];
+              }
+        }
     __syncthreads();
     // x sweep: line = (y=u, z=v): out = h (Kx c + Mx g)
 #pragma unroll
@@ -376,6 +481,25 @@ namespace mgamd
               bufA[base + i] = h * r2[i];
           }
       }
+    if constexpr (SEGMENTS)
+      if (sg)
+        {
+          const T   h    = T(hslot[0]);
+          const int base = (sg_v * N + sg_u) * N + 4 * sg_s;
+          T         a[P + 5], b[P + 5], o1[5], o2[5];
+#pragma unroll
+          for (int i = 0; i < P + 5; ++i)
+            {
+              a[i] = (sg_s > 0 || i >= P) ? bufA[base + (i - P)] : T(0);
+              b[i] = (sg_s > 0 || i >= P) ? bufB[base + (i - P)] : T(0);
+            }
+          seg_fence();
+          seg_products<T, P, 2>(m, a, b, sg_s > 0, o1, o2);
+#pragma unroll
+          for (int i = 0; i < 5; ++i)
+            if (i < 4 || sg_s == 3)
+              bufA[base + i] = h * o2[i];
+        }
     __syncthreads();
   }
 

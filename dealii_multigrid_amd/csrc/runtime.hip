@@ -4,6 +4,8 @@
 
 #include <chrono>
 #include <cmath>
+#include <mutex>
+#include <set>
 
 namespace mgamd
 {
@@ -25,6 +27,10 @@ namespace mgamd
     if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
       throw NoDeviceError(std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
     HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    HIP_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    sync_events.resize(64);
+    for (hipEvent_t &e : sync_events)
+      HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_CHECK(hipMalloc((void **)&d_partial, 1024 * sizeof(double)));
     HIP_CHECK(hipMalloc((void **)&d_result, 8 * sizeof(double)));
     HIP_CHECK(hipHostMalloc((void **)&h_result, 8 * sizeof(double)));
@@ -33,6 +39,10 @@ namespace mgamd
   Ctx::~Ctx()
   {
     (void)hipStreamSynchronize(stream);
+    (void)hipStreamSynchronize(side);
+    for (hipEvent_t e : sync_events)
+      (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(side);
     for (auto &p : prof_events)
       {
         (void)hipEventDestroy(p.first);
@@ -211,9 +221,20 @@ namespace mgamd
   // ------------------------------------------------------------------------------------------
   // Level operator
   // ------------------------------------------------------------------------------------------
+  // hipFuncAttributeMaxDynamicSharedMemorySize once per (device, kernel); callers may be concurrent host threads (SimComm)
+  static void
+  ensure_dynamic_lds(Ctx *ctx, const void *kern, size_t lds)
+  {
+    static std::mutex                             m;
+    static std::set<std::pair<int, const void *>> done;
+    std::lock_guard<std::mutex>                   lock(m);
+    if (done.insert({ctx->device, kern}).second)
+      HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
+
   template <typename T, int P, int B, int MODE>
   static void
-  launch_lattice(Ctx *ctx, const ApplyArgs<T, P> &a, bool diag)
+  launch_lattice(Ctx *ctx, hipStream_t st, const ApplyArgs<T, P> &a, bool diag)
   {
     using G = Geo<P, B>;
     if (a.g.n_slots == 0)
@@ -223,63 +244,53 @@ namespace mgamd
       {
         const size_t lds  = 3 * (size_t)G::SPW * G::N3 * sizeof(T);
         auto         kern = lattice_diag_kernel<T, P, B>;
-        static bool  once = false;
-        if (!once)
-          {
-            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            once = true;
-          }
-        hipLaunchKernelGGL(kern, grid, G::BLOCK, lds, ctx->stream, a);
+        ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), lds);
+        hipLaunchKernelGGL(kern, grid, G::BLOCK, lds, st, a);
       }
     else
       {
         const size_t lds  = (2 * (size_t)G::SPW * G::N3 + 2 * P * P * P + G::SPW) * sizeof(T);
         auto         kern = lattice_apply_kernel<T, P, B, MODE>;
-        static bool  once = false;
-        if (!once)
-          {
-            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            once = true;
-          }
-        hipLaunchKernelGGL(kern, grid, G::ABLOCK, lds, ctx->stream, a);
+        ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), lds);
+        hipLaunchKernelGGL(kern, grid, G::ABLOCK, lds, st, a);
       }
     HIP_CHECK(hipGetLastError());
   }
 
   template <typename T, int P, int MODE>
   static void
-  dispatch_B(Ctx *ctx, int B, const ApplyArgs<T, P> &a, bool diag)
+  dispatch_B(Ctx *ctx, hipStream_t st, int B, const ApplyArgs<T, P> &a, bool diag)
   {
     switch (B)
       {
         case 1:
-          launch_lattice<T, P, 1, MODE>(ctx, a, diag);
+          launch_lattice<T, P, 1, MODE>(ctx, st, a, diag);
           return;
         case 2:
           if constexpr (P * 2 + 1 <= 17)
             {
-              launch_lattice<T, P, 2, MODE>(ctx, a, diag);
+              launch_lattice<T, P, 2, MODE>(ctx, st, a, diag);
               return;
             }
           break;
         case 4:
           if constexpr (P * 4 + 1 <= 17)
             {
-              launch_lattice<T, P, 4, MODE>(ctx, a, diag);
+              launch_lattice<T, P, 4, MODE>(ctx, st, a, diag);
               return;
             }
           break;
         case 8:
           if constexpr (P * 8 + 1 <= 17)
             {
-              launch_lattice<T, P, 8, MODE>(ctx, a, diag);
+              launch_lattice<T, P, 8, MODE>(ctx, st, a, diag);
               return;
             }
           break;
         case 16:
           if constexpr (P * 16 + 1 <= 17)
             {
-              launch_lattice<T, P, 16, MODE>(ctx, a, diag);
+              launch_lattice<T, P, 16, MODE>(ctx, st, a, diag);
               return;
             }
           break;
@@ -300,6 +311,14 @@ namespace mgamd
     view() const
     {
       return SlotGroupDev{interior_base.p, shell_idx.p, mask.p, h.p, shell_pos.p, (uint32_t)n_slots, fmask.p};
+    }
+    // slots [begin, end) only (a chunk of the pipelined pass)
+    SlotGroupDev
+    view(size_t begin, size_t end) const
+    {
+      const size_t n_shell = (size_t)N * N * N - (size_t)(N - 2) * (N - 2) * (N - 2);
+      return SlotGroupDev{interior_base.p + begin, shell_idx.p + begin * n_shell, mask.p + begin, h.p + begin, shell_pos.p,
+                          (uint32_t)(end - begin), fmask.p ? fmask.p + begin : nullptr};
     }
     // single cells at p = 1: per-cluster distinct node lists for cell_cluster_apply_kernel
     DBuf<uint32_t> uniq_ptr, uniq_idx;
@@ -539,7 +558,7 @@ namespace mgamd
     }
 
     void
-    launch_clusters(const GroupDev<T> &g, const T *src, const Epilogue<T> &epi, bool first)
+    launch_clusters(hipStream_t st, const GroupDev<T> &g, const T *src, const Epilogue<T> &epi, bool first)
     {
       ClusterArgs<T> a;
       a.c          = g.cluster_view();
@@ -552,10 +571,81 @@ namespace mgamd
       a.c0         = epi.c0;
       a.from_b     = first ? 1 : 0;
       const uint32_t grid = (uint32_t)((g.n_slots + CLUSTER_CELLS - 1) / CLUSTER_CELLS);
-      hipLaunchKernelGGL(cell_cluster_apply_kernel<T>, grid, CLUSTER_CELLS, 2 * (size_t)std::max<uint32_t>(g.max_uniq, 1) * sizeof(T), ctx->stream, a);
+      hipLaunchKernelGGL(cell_cluster_apply_kernel<T>, grid, CLUSTER_CELLS, 2 * (size_t)std::max<uint32_t>(g.max_uniq, 1) * sizeof(T), st, a);
       HIP_CHECK(hipGetLastError());
     }
 
+    // launches of one slot group (with its merge partner, if any) on stream st; [begin, end) restricts an unmerged group
+    // to a slot range
+    template <int P, int MODE>
+    void
+    launch_group(hipStream_t st, ApplyArgs<T, P> &a, GroupDev<T> *g, GroupDev<T> *partner_cells, GroupDev<T> *partner_clusters,
+                 const T *src, const Epilogue<T> &epi, bool diag, size_t begin, size_t end)
+    {
+      a.g      = (begin == 0 && end == g->n_slots) ? g->view() : g->view(begin, end);
+      a.stamps = (stamps.p && g->B == prof_B && MODE == stamp_mode && !diag && begin == 0) ? stamps.p : nullptr;
+      if (partner_clusters)
+        {
+          if constexpr (P == 1)
+            {
+              using G8 = Geo<1, 8>;
+              GroupDev<T>   *gc = partner_clusters;
+              P1SmallArgs<T> sa;
+              sa.a           = a;
+              sa.c           = cluster_args(*gc, src, epi, MODE == MODE_CHEB_FIRST);
+              sa.n_wg_bricks = (uint32_t)((g->n_slots + G8::SPW - 1) / G8::SPW);
+              const uint32_t n_wg_cl = (uint32_t)((gc->n_slots + CLUSTER_CELLS - 1) / CLUSTER_CELLS);
+              const size_t   lds     = std::max((2 * (size_t)G8::SPW * G8::N3 + 2 + G8::SPW) * sizeof(T),
+                                          2 * (size_t)std::max<uint32_t>(gc->max_uniq, 1) * sizeof(T));
+              hipLaunchKernelGGL((lattice_cluster_kernel<T, MODE>), sa.n_wg_bricks + n_wg_cl, 256, lds, st, sa);
+              HIP_CHECK(hipGetLastError());
+            }
+        }
+      else if (P == 1 && !diag && g->has_clusters())
+        launch_clusters(st, *g, src, epi, MODE == MODE_CHEB_FIRST);
+      else if (partner_cells)
+        {
+          if constexpr (P >= 2)
+            {
+              using G2 = Geo<P, 2>;
+              using G1 = Geo<P, 1>;
+              GroupDev<T>         *g1 = partner_cells;
+              SmallSlotsArgs<T, P> sa;
+              sa.a           = a;
+              sa.g_cells     = g1->view();
+              sa.n_wg_bricks = (uint32_t)((g->n_slots + G2::SPW - 1) / G2::SPW);
+              const uint32_t n_wg_cells = (uint32_t)((g1->n_slots + G1::SPW - 1) / G1::SPW);
+              const size_t   lds = (std::max(2 * (size_t)G2::SPW * G2::N3, 2 * (size_t)G1::SPW * G1::N3) + 2 * P * P * P + std::max(G2::SPW, G1::SPW)) * sizeof(T);
+              hipLaunchKernelGGL((lattice_apply_small_kernel<T, P, MODE>), sa.n_wg_bricks + n_wg_cells, 256, lds, st, sa);
+              HIP_CHECK(hipGetLastError());
+            }
+        }
+      else
+        dispatch_B<T, P, MODE>(ctx, st, g->B, a, diag);
+    }
+
+    template <int MODE>
+    void
+    launch_tail(hipStream_t st, uint32_t begin, uint32_t end, bool with_rest, const Epilogue<T> &epi, bool diag)
+    {
+      const uint32_t n_rest = with_rest ? tables->n_dofs - tables->n_interior - tables->n_tail : 0;
+      const uint32_t n_t    = end - begin + n_rest;
+      if (!n_t)
+        return;
+      if (diag)
+        hipLaunchKernelGGL((tail_kernel<T, MODE_INVDIAG>), grid_for(n_t), 256, 0, st, tail_acc.p + begin, tables->n_interior + begin, end - begin,
+                           n_rest, epi);
+      else
+        hipLaunchKernelGGL((tail_kernel<T, MODE>), grid_for(n_t), 256, 0, st, tail_acc.p + begin, tables->n_interior + begin, end - begin, n_rest,
+                           epi);
+      HIP_CHECK(hipGetLastError());
+    }
+
+    // One operator application.  Large levels run as a PIPELINE over two queues: the bricks of the dominant group go
+    // out in Morton chunks on the main queue; the small-slot kernels and, chunk by chunk, the epilogue of the tail DoFs
+    // that are complete after that chunk (LevelTables::tail_stage_end) run on the side queue underneath the next chunks.
+    // The brick kernel is latency-bound (2 workgroups per CU, sweeps between the memory phases), the tail epilogue is a
+    // pure stream without LDS: they share the CUs instead of running one after the other.
     template <int P, int MODE>
     void
     apply_P(const T *src, const Epilogue<T> &epi, bool diag, double words)
@@ -590,85 +680,72 @@ namespace mgamd
               gc = g.get();
           }
       const bool merged_p1 = g8 && gc;
-      for (auto &g : groups)
+
+      const int         pg        = tables->pipeline_group;
+      const bool        pipelined = !diag && pg >= 0 && !tables->chunk_slot_end.empty() && groups[pg]->n_slots > 0;
+      const hipStream_t main = ctx->stream, side = pipelined ? ctx->side : ctx->stream;
+      if (pipelined)
+        ctx->order_after(side, main); // the side queue starts where the main queue stands
+      auto prof_begin = [&](const GroupDev<T> &g) {
+        const bool prof = ctx->profile && !diag && MODE == MODE_CHEB && g.B == (ctx->prof_brick ? ctx->prof_brick : prof_B);
+        if (prof)
+          {
+            if (ctx->prof_used == ctx->prof_events.size())
+              {
+                hipEvent_t e0, e1;
+                HIP_CHECK(hipEventCreate(&e0));
+                HIP_CHECK(hipEventCreate(&e1));
+                ctx->prof_events.push_back({e0, e1});
+              }
+            HIP_CHECK(hipEventRecord(ctx->prof_events[ctx->prof_used].first, main));
+          }
+        return prof;
+      };
+      auto prof_end = [&](const GroupDev<T> &g, size_t n_slots) {
+        HIP_CHECK(hipEventRecord(ctx->prof_events[ctx->prof_used].second, main));
+        ++ctx->prof_used;
+        const double n1 = (double)(g.N - 1);
+        ctx->prof_bytes += words * sizeof(T) * (double)n_slots * n1 * n1 * n1;
+      };
+      // every group but the pipelined one
+      for (size_t gi = 0; gi < groups.size(); ++gi)
         {
-          if (!g->n_slots)
+          GroupDev<T> *g = groups[gi].get();
+          if (!g->n_slots || (pipelined && (int)gi == pg))
             continue;
-          if ((merged && g.get() == g1) || (merged_p1 && g.get() == gc))
+          if ((merged && g == g1) || (merged_p1 && g == gc))
             continue; // done together with the 2^3 (8^3) bricks
-          a.g      = g->view();
-          a.stamps = (stamps.p && g->B == prof_B && MODE == stamp_mode && !diag) ? stamps.p : nullptr;
-          const bool prof = ctx->profile && !diag && MODE == MODE_CHEB && g->B == (ctx->prof_brick ? ctx->prof_brick : prof_B);
+          const bool prof = !pipelined && prof_begin(*g);
+          launch_group<P, MODE>(side, a, g, (merged && g == g2) ? g1 : nullptr, (merged_p1 && g == g8) ? gc : nullptr, src, epi, diag, 0,
+                                g->n_slots);
           if (prof)
+            prof_end(*g, g->n_slots);
+        }
+      uint32_t tail_done = 0;
+      if (pipelined)
+        {
+          GroupDev<T> *g     = groups[pg].get();
+          uint32_t     begin = 0;
+          for (size_t c = 0; c < tables->chunk_slot_end.size(); ++c)
             {
-              if (ctx->prof_used == ctx->prof_events.size())
+              const uint32_t end  = tables->chunk_slot_end[c];
+              const bool     prof = prof_begin(*g);
+              launch_group<P, MODE>(main, a, g, nullptr, nullptr, src, epi, diag, begin, end);
+              if (prof)
+                prof_end(*g, end - begin);
+              begin = end;
+              if (tables->tail_stage_end[c] > tail_done)
                 {
-                  hipEvent_t e0, e1;
-                  HIP_CHECK(hipEventCreate(&e0));
-                  HIP_CHECK(hipEventCreate(&e1));
-                  ctx->prof_events.push_back({e0, e1});
-                }
-              HIP_CHECK(hipEventRecord(ctx->prof_events[ctx->prof_used].first, ctx->stream));
-            }
-          if (merged_p1 && g.get() == g8)
-            {
-              if constexpr (P == 1)
-                {
-                  using G8 = Geo<1, 8>;
-                  P1SmallArgs<T> sa;
-                  sa.a           = a;
-                  sa.c           = cluster_args(*gc, src, epi, MODE == MODE_CHEB_FIRST);
-                  sa.n_wg_bricks = (uint32_t)((g8->n_slots + G8::SPW - 1) / G8::SPW);
-                  const uint32_t n_wg_cl = (uint32_t)((gc->n_slots + CLUSTER_CELLS - 1) / CLUSTER_CELLS);
-                  const size_t   lds     = std::max((2 * (size_t)G8::SPW * G8::N3 + 2 + G8::SPW) * sizeof(T),
-                                              2 * (size_t)std::max<uint32_t>(gc->max_uniq, 1) * sizeof(T));
-                  hipLaunchKernelGGL((lattice_cluster_kernel<T, MODE>), sa.n_wg_bricks + n_wg_cl, 256, lds, ctx->stream, sa);
-                  HIP_CHECK(hipGetLastError());
+                  ctx->order_after(side, main);
+                  launch_tail<MODE>(side, tail_done, tables->tail_stage_end[c], false, epi, diag);
+                  tail_done = tables->tail_stage_end[c];
                 }
             }
-          else if (P == 1 && !diag && g->has_clusters())
-            launch_clusters(*g, src, epi, MODE == MODE_CHEB_FIRST);
-          else if (merged && g.get() == g2)
-            {
-              if constexpr (P >= 2)
-                {
-                  using G2 = Geo<P, 2>;
-                  using G1 = Geo<P, 1>;
-                  SmallSlotsArgs<T, P> sa;
-                  sa.a           = a;
-                  sa.g_cells     = g1->view();
-                  sa.n_wg_bricks = (uint32_t)((g2->n_slots + G2::SPW - 1) / G2::SPW);
-                  const uint32_t n_wg_cells = (uint32_t)((g1->n_slots + G1::SPW - 1) / G1::SPW);
-                  const size_t   lds = (std::max(2 * (size_t)G2::SPW * G2::N3, 2 * (size_t)G1::SPW * G1::N3) + 2 * P * P * P + std::max(G2::SPW, G1::SPW)) * sizeof(T);
-                  hipLaunchKernelGGL((lattice_apply_small_kernel<T, P, MODE>), sa.n_wg_bricks + n_wg_cells, 256, lds, ctx->stream, sa);
-                  HIP_CHECK(hipGetLastError());
-                }
-            }
-          else
-            dispatch_B<T, P, MODE>(ctx, g->B, a, diag);
-          if (prof)
-            {
-              HIP_CHECK(hipEventRecord(ctx->prof_events[ctx->prof_used].second, ctx->stream));
-              ++ctx->prof_used;
-              const double n1 = (double)(g->N - 1);
-              ctx->prof_bytes += words * sizeof(T) * (double)g->n_slots * n1 * n1 * n1;
-            }
+          ctx->order_after(main, side); // join
         }
       if (halo)
         exchange_add_raw(tail_acc.p); // complete the shared tail sums across ranks before the epilogue
-      const uint32_t n_rest = tables->n_dofs - tables->n_interior - tables->n_tail;
-      const uint32_t n_t    = tables->n_tail + n_rest;
-      if (n_t)
-        {
-          constexpr int TM = MODE;
-          if (diag)
-            hipLaunchKernelGGL((tail_kernel<T, MODE_INVDIAG>), grid_for(n_t), 256, 0, ctx->stream, tail_acc.p, tables->n_interior,
-                               tables->n_tail, n_rest, epi);
-          else
-            hipLaunchKernelGGL((tail_kernel<T, TM>), grid_for(n_t), 256, 0, ctx->stream, tail_acc.p, tables->n_interior, tables->n_tail,
-                               n_rest, epi);
-          HIP_CHECK(hipGetLastError());
-        }
+      launch_tail<MODE>(main, tail_done, tables->n_tail, true, epi, diag);
     }
 
     template <int MODE>
@@ -1562,6 +1639,7 @@ namespace mgamd
 
     ~MultigridT() override
     {
+      release_stage_records();
       if (graph_exec)
         (void)hipGraphExecDestroy(graph_exec);
     }
@@ -1640,6 +1718,29 @@ namespace mgamd
           ctx->sync();
           cb(s, start ? 1 : 0, level, cb_user);
         }
+      if (stage_timing)
+        {
+          if (start)
+            {
+              if (stage_used == stage_records.size())
+                {
+                  StageRecord r{s, level, nullptr, nullptr};
+                  HIP_CHECK(hipEventCreate(&r.e0));
+                  HIP_CHECK(hipEventCreate(&r.e1));
+                  stage_records.push_back(r);
+                }
+              stage_records[stage_used].stage = s;
+              stage_records[stage_used].level = level;
+              HIP_CHECK(hipEventRecord(stage_records[stage_used].e0, ctx->stream));
+            }
+          else
+            HIP_CHECK(hipEventRecord(stage_records[stage_used++].e1, ctx->stream));
+        }
+    }
+    unsigned
+    n_levels() const override
+    {
+      return nl;
     }
 
     void
@@ -1698,9 +1799,14 @@ namespace mgamd
         }
       if (l == collapse_level && !cb)
         {
+          // the tabulated cycle below this level: timed as the coarse solve of level l
           const size_t n = ops[l]->n_dofs();
+          if (stage_timing)
+            stage(3, true, l);
           hipLaunchKernelGGL(dense_matvec_kernel<T>, (int)std::min<size_t>(n, 1024), 256, 0, ctx->stream, collapse_M.p, dview[l], sview[l],
                              (int)n);
+          if (stage_timing)
+            stage(3, false, l);
           sol[l] = sview[l];
           return;
         }
@@ -1732,11 +1838,7 @@ namespace mgamd
       const unsigned L    = nl - 1;
       const bool     same = sizeof(TO) == sizeof(T) && nl > 1;
       // copy_to_mg: defect_L = cast(r), coarser defects zero
-      if (cb)
-        {
-          ctx->sync();
-          cb(7, 1, L, cb_user);
-        }
+      stage(7, true, L);
       if (same)
         {
           // r is the finest defect; z takes the role of the smoother buffer the post-smoother ends in
@@ -1765,24 +1867,12 @@ namespace mgamd
         }
       if (nl > 1)
         defect_slab.zero(ctx->stream);
-      if (cb)
-        {
-          ctx->sync();
-          cb(7, 0, L, cb_user);
-        }
+      stage(7, false, L);
       level_v_step(L);
-      if (cb)
-        {
-          ctx->sync();
-          cb(8, 1, L, cb_user);
-        }
+      stage(8, true, L);
       if ((const void *)sol[L] != (const void *)z)
         hipLaunchKernelGGL((vec_copy_kernel<TO, T>), grid_for(n), 256, 0, ctx->stream, z, sol[L], n);
-      if (cb)
-        {
-          ctx->sync();
-          cb(8, 0, L, cb_user);
-        }
+      stage(8, false, L);
     }
 
     void
@@ -1802,8 +1892,8 @@ namespace mgamd
     {
       if (n == 0)
         return 0.0;
-      if (cb)
-        throw std::invalid_argument("time_vcycles: remove the stage callback first");
+      if (cb || stage_timing)
+        throw std::invalid_argument("time_vcycles: remove the stage callback / stage timing first");
       const bool graphable = coarse_type == "direct" && !ops[nl - 1]->comm;
       vcycle(z, r); // warm-up: sets kernel attributes, touches memory
       ctx->sync();

@@ -44,12 +44,27 @@ namespace mgamd
     double                                         prof_ms_accum = 0.0; // already harvested
     uint64_t                                       prof_n_accum  = 0;
 
+    // second queue of the pipelined operator pass (small-slot kernels and tail stages overlap with the brick chunks) and a
+    // ring of timing-free events for the cross-queue ordering
+    hipStream_t             side = nullptr;
+    std::vector<hipEvent_t> sync_events;
+    size_t                  sync_next = 0;
+
     explicit Ctx(int dev);
     ~Ctx();
     void
     sync()
     {
       HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    // `to` waits for everything enqueued on `from` so far
+    void
+    order_after(hipStream_t to, hipStream_t from)
+    {
+      hipEvent_t e = sync_events[sync_next];
+      sync_next    = (sync_next + 1) % sync_events.size();
+      HIP_CHECK(hipEventRecord(e, from));
+      HIP_CHECK(hipStreamWaitEvent(to, e, 0));
     }
     void
     harvest_profile();
@@ -215,6 +230,52 @@ namespace mgamd
     vcycle(mgamd_vec &z, const mgamd_vec &r) = 0; // PreconditionMG::vmult
     virtual double
     time_vcycles(mgamd_vec &z, const mgamd_vec &r, unsigned n, bool use_graph) = 0;
+    virtual unsigned
+    n_levels() const = 0;
+
+    // Stage times without host synchronisation: a HIP event pair is recorded on the stream around every stage of the
+    // UNCHANGED cycle (same code path as an un-instrumented cycle, collapsed coarse levels included) and resolved when read.
+    struct StageRecord
+    {
+      int        stage;
+      unsigned   level;
+      hipEvent_t e0, e1;
+    };
+    bool                     stage_timing = false;
+    std::vector<StageRecord> stage_records;
+    size_t                   stage_used = 0;
+    void
+    set_stage_timing(bool on)
+    {
+      ctx->sync();
+      stage_timing = on;
+      stage_used   = 0;
+    }
+    // ms[stage * n_levels + level] += elapsed; returns the number of records consumed
+    size_t
+    read_stage_times(double *ms)
+    {
+      ctx->sync();
+      for (size_t i = 0; i < stage_used; ++i)
+        {
+          float t = 0;
+          HIP_CHECK(hipEventElapsedTime(&t, stage_records[i].e0, stage_records[i].e1));
+          ms[(size_t)stage_records[i].stage * n_levels() + stage_records[i].level] += t;
+        }
+      const size_t n = stage_used;
+      stage_used     = 0;
+      return n;
+    }
+    void
+    release_stage_records()
+    {
+      for (auto &r : stage_records)
+        {
+          (void)hipEventDestroy(r.e0);
+          (void)hipEventDestroy(r.e1);
+        }
+      stage_records.clear();
+    }
   };
 
   LevelOperatorBase *

@@ -91,6 +91,12 @@ typedef struct
 int mgamd_dofs_create(const mgamd_tria *t, int degree, int max_brick, mgamd_dofs **out);
 int mgamd_dofs_destroy(mgamd_dofs *d);
 int mgamd_dofs_info(const mgamd_dofs *d, mgamd_dofs_info_t *info);
+/* pipelined operator pass: the slots of group `*group` (-1: level not pipelined) are launched in
+ * *n_chunks Morton chunks ending at chunk_slot_end[c]; the owned tail DoFs [tail_stage_end[c-1], tail_stage_end[c]) (tail
+ * indices = global index - n_interior) are complete once chunk c has run.  Arrays of up to 16 entries, may be NULL. */
+int mgamd_dofs_pipeline(const mgamd_dofs *d, int *group, uint32_t *n_chunks, uint32_t *chunk_slot_end, uint32_t *tail_stage_end);
+/* slot group and slot index of every cell (0xFE: cell of another rank) */
+int mgamd_dofs_get_cell_slots(const mgamd_dofs *d, uint8_t *group, uint32_t *slot);
 /* geometric identity of each DoF: keys[5*i..] = {px,py,pz,dirmask,level} (tests / oracle matching) */
 int mgamd_dofs_get_keys(const mgamd_dofs *d, int32_t *keys);
 /* per cell (p+1)^3 gathered DoF indices, x fastest; hanging entities resolved to the parent's
@@ -235,6 +241,13 @@ int mgamd_mg_vcycle(mgamd_mg *mg, mgamd_vec *z, const mgamd_vec *r);
  * and synchronises the stream around every stage so host clocks are meaningful. */
 typedef void (*mgamd_stage_callback)(int stage, int start, unsigned level, void *user);
 int mgamd_mg_set_stage_callback(mgamd_mg *mg, mgamd_stage_callback cb, void *user);
+/* Stage times WITHOUT host synchronisation: while enabled, a HIP event pair is recorded on the stream around every stage
+ * of the unchanged cycle (collapsed coarse levels included: they appear as the coarse solve, stage 3, of the collapse
+ * level).  mgamd_mg_stage_times synchronises once, ADDS the elapsed milliseconds of all stages recorded since the last
+ * read to ms[stage * n_levels + level] (9 x n_levels entries) and returns the number of stage records consumed.  This is
+ * how the harness fills the reference's time_pre ... time_to_global columns (ref:multigrid_throughput.cc:1381-1401). */
+int mgamd_mg_stage_timing(mgamd_mg *mg, int enable);
+int mgamd_mg_stage_times(mgamd_mg *mg, double *ms, unsigned n_levels, uint64_t *n_records);
 /* run `n` V-cycles back to back and return the average time per cycle in milliseconds, measured
  * with HIP events on the context's stream (bench.py / harness). use_graph != 0 replays a captured
  * hipGraph of one cycle. */

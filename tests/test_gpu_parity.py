@@ -15,7 +15,10 @@ TOL_SOL = 1e-10
 
 OP_CASES = [("quadrant", 3, 1, 0), ("quadrant", 3, 1, 1), ("quadrant", 4, 1, 0), ("quadrant", 3, 2, 0), ("quadrant", 3, 3, 0),
             ("quadrant", 3, 4, 0), ("quadrant", 3, 4, 1), ("hypercube", 3, 1, 0), ("hypercube", 4, 1, 0), ("hypercube", 2, 4, 0),
-            ("hypercube", 3, 2, 0), ("annulus", 5, 2, 0), ("annulus", 5, 1, 0), ("quadrant", 0, 4, 0), ("quadrant", 1, 1, 0)]
+            ("hypercube", 3, 2, 0), ("annulus", 5, 2, 0), ("annulus", 5, 1, 0), ("quadrant", 0, 4, 0), ("quadrant", 1, 1, 0),
+            # several 17^3-lattice bricks that share faces, edges and a vertex (the dominant kernels of the bench workloads:
+            # 4^3-cell bricks at p = 4, 16^3-cell bricks at p = 1) against the INDEPENDENT numpy oracle
+            ("hypercube", 3, 4, 0), ("hypercube", 5, 1, 0), ("quadrant", 4, 2, 0)]
 
 
 @pytest.fixture(scope="module")
@@ -99,7 +102,7 @@ def test_chebyshev(mgamd, oracle, ctx, levels, geo, L, p, max_brick, degree):
 HIER_CASES = [("quadrant", 3, 1, "HMG-global"), ("quadrant", 4, 1, "HMG-global"), ("quadrant", 3, 2, "HMG-global"),
               ("quadrant", 3, 4, "HMG-global"), ("hypercube", 3, 1, "HMG-global"), ("hypercube", 2, 4, "HMG-global"),
               ("annulus", 5, 2, "HMG-global"), ("quadrant", 3, 4, "PMG"), ("annulus", 5, 2, "PMG"), ("quadrant", 3, 3, "PMG"),
-              ("quadrant", 3, 4, "HPMG"), ("annulus", 5, 2, "HPMG")]
+              ("quadrant", 3, 4, "HPMG"), ("annulus", 5, 2, "HPMG"), ("hypercube", 3, 4, "HMG-global"), ("hypercube", 5, 1, "HMG-global")]
 
 
 @pytest.fixture(scope="module")
@@ -293,3 +296,91 @@ def test_gaussian_simulation_type_solve(mgamd, oracle, ctx, hierarchies, geo, L,
     assert rel_err(x.to_host(), xref) < TOL_SOL
     h.fine_operator.distribute(x, 1)
     assert rel_err(x.to_host(), Lf.distribute(xref, oracle.gaussian_solution)) < 10 * TOL_SOL
+
+
+@pytest.mark.parametrize("geo,L,p,chunks", [("hypercube", 3, 4, 3), ("hypercube", 5, 1, 4), ("hypercube", 4, 2, 2)])
+def test_pipelined_operator_pass(mgamd, oracle, ctx, geo, L, p, chunks, monkeypatch):
+    """Large levels run the operator as a two-queue pipeline (brick chunks on the main queue, small slots and the staged
+    tail epilogue on the side queue).  Forced here on small meshes: every mode of the fused kernels
+    (vmult, residual inside the V-cycle, the three Chebyshev variants) against the numpy oracle, and identical to the
+    un-pipelined pass."""
+    monkeypatch.setenv("MGAMD_PIPELINE", "1")
+    monkeypatch.setenv("MGAMD_PIPELINE_MIN_SLOTS", "1")
+    monkeypatch.setenv("MGAMD_PIPELINE_CHUNKS", str(chunks))
+    h = mgamd.Hierarchy(ctx, geo, L, p, "HMG-global", coarse_solver="amg", max_brick=0)
+    grp, chunk_end, stage_end = h.dofs[-1].pipeline()
+    assert grp >= 0 and len(chunk_end) == chunks and stage_end[0] > 0
+    levels, P = oracle.build_hierarchy(geo, L, p, "HMG-global", numbering_keys=[d.keys() for d in h.dofs])
+    lv, op = levels[-1], h.operators[-1]
+    rng = np.random.default_rng(31)
+    x, b = rng.standard_normal(lv.n), rng.standard_normal(lv.n)
+    src, dst = op.initialize_dof_vector().from_host(x), op.initialize_dof_vector()
+    for _ in range(3):  # repeated: the accumulator must be clean after every pass
+        op.vmult(dst, src)
+        assert rel_err(dst.to_host(), lv.A @ x) < TOL_OP
+    for degree in (1, 2, 3, 4):
+        ch = mgamd.PreconditionChebyshev(op, degree, 20.0, 20)
+        ref = oracle.Chebyshev(lv.A, lv.inv_diag, degree, 20.0, 20)
+        vb, vx = op.initialize_dof_vector().from_host(b), op.initialize_dof_vector()
+        ch.vmult(vx, vb)
+        assert rel_err(vx.to_host(), ref.vmult(b)) < 1e-12
+        vx.from_host(x)
+        ch.step(vx, vb)
+        assert rel_err(vx.to_host(), ref.step(x, b)) < 1e-12
+    mg = oracle.Multigrid(levels, P, 3, coarse="direct")
+    vr, vz = mgamd.Vector(ctx, lv.n).from_host(b), mgamd.Vector(ctx, lv.n)
+    for _ in range(2):
+        h.mg.vmult(vz, vr)
+        assert rel_err(vz.to_host(), mg.vcycle(b)) < 1e-11
+    xref, itref, hist = oracle.pcg(lv.A, lv.rhs_constant, mg.vcycle, 1e-4)
+    vb2, vx2 = h.fine_operator.initialize_dof_vector(), h.fine_operator.initialize_dof_vector()
+    h.fine_operator.rhs(vb2)
+    it, res = mgamd.solve_cg(h.fine_operator, h.mg, vx2, vb2, 1e-4)
+    assert it == itref and rel_err(vx2.to_host(), xref) < TOL_SOL
+
+
+def test_pipelined_pass_at_scale_matches_unpipelined(mgamd, ctx, monkeypatch):
+    """octant L=6 p=4 (2.3 M DoFs, 343 bricks of 4^3 cells + constrained families + single cells) and octant L=8 p=1: the
+    pipelined V-cycle equals the un-pipelined one through the DoF keys (different tail numbering, same operator)."""
+    for geo, L, p in (("quadrant", 6, 4), ("quadrant", 8, 1)):
+        monkeypatch.setenv("MGAMD_CHEB_KEY_INIT", "1")
+        monkeypatch.setenv("MGAMD_PIPELINE", "1")
+        monkeypatch.setenv("MGAMD_PIPELINE_MIN_SLOTS", "1")
+        ha = mgamd.Hierarchy(ctx, geo, L, p, "HMG-global", coarse_solver="amg")
+        assert ha.dofs[-1].pipeline()[0] >= 0
+        monkeypatch.setenv("MGAMD_PIPELINE_MIN_SLOTS", "1000000000")
+        hb = mgamd.Hierarchy(ctx, geo, L, p, "HMG-global", coarse_solver="amg")
+        assert hb.dofs[-1].pipeline()[0] < 0
+        ka, kb = ha.dofs[-1].keys(), hb.dofs[-1].keys()
+        pos = {tuple(k): i for i, k in enumerate(kb.tolist())}
+        perm = np.array([pos[tuple(k)] for k in ka.tolist()])
+        rb = np.random.default_rng(5).standard_normal(len(kb))
+        za, zb = mgamd.Vector(ctx, len(ka)), mgamd.Vector(ctx, len(kb))
+        ha.mg.vmult(za, mgamd.Vector(ctx, len(ka)).from_host(rb[perm]))
+        hb.mg.vmult(zb, mgamd.Vector(ctx, len(kb)).from_host(rb))
+        assert rel_err(za.to_host(), zb.to_host()[perm]) < 1e-11
+
+
+def test_event_stage_timing(mgamd, ctx):
+    """HIP-event stage timing (what the harness uses for the reference's time_* columns): same cycle, every stage of
+    every level recorded, the collapsed coarse levels reported as the coarse solve of the collapse level, and the stage
+    times add up to the cycle time."""
+    h = mgamd.Hierarchy(ctx, "quadrant", 5, 4, "HMG-global", coarse_solver="amg")
+    n = h.n_dofs
+    r = np.random.default_rng(9).standard_normal(n)
+    vr, vz = mgamd.Vector(ctx, n).from_host(r), mgamd.Vector(ctx, n)
+    h.mg.vmult(vz, vr)
+    ref = vz.to_host()
+    h.mg.stage_timing(True)
+    for _ in range(3):
+        h.mg.vmult(vz, vr)
+    ms = h.mg.stage_times() / 3
+    h.mg.stage_timing(False)
+    assert rel_err(vz.to_host(), ref) < 1e-13  # (atomic accumulation order differs from run to run)
+    nl = len(h.dofs)
+    assert (ms >= 0).all() and ms[0, nl - 1] > 0 and ms[6, nl - 1] > 0 and ms[1, nl - 1] > 0
+    assert ms[5].sum() < 0.2 * ms.sum()  # edge prolongation: empty for global coarsening
+    cs = np.nonzero(ms[3])[0]
+    assert len(cs) == 1 and ms[0, : cs[0] + 1].sum() == 0  # one coarse "solve"; nothing is smoothed at or below it
+    t = h.mg.time_vcycles(vz, vr, 5, False)
+    assert 0.5 * t < ms.sum() < 2.0 * t

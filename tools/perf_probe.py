@@ -26,22 +26,19 @@ for geo, L, p in cases:
     by = algorithmic_bytes(N)
     print(f"{geo} L={L} p={p}: n_dofs={n} setup {t1-t0:.1f}s  eager {ms_e:.3f} ms  graph {ms_g:.3f} ms  "
           f"-> {n/ms_g*1e3:.3e} DoF/s, algorithmic {by/n:.1f} B/DoF -> {by/ms_g*1e-9:.3f} TB/s = {by/ms_g*1e-9/8.0*100:.1f}% of 8 TB/s", flush=True)
-    # per-stage breakdown (eager, synchronised)
-    acc = {}
-    t_last = [0.0]
-    def cb(s, start, lv):
-        if start:
-            t_last[0] = time.perf_counter()
-        else:
-            acc[(s, lv)] = acc.get((s, lv), 0.0) + time.perf_counter() - t_last[0]
-    h.mg.connect_stages(cb)
-    for _ in range(3):
+    # per-level x per-stage breakdown of the SAME cycle: HIP events on the stream, no host synchronisation
+    reps = 5
+    h.mg.stage_timing(True)
+    for _ in range(reps):
         h.mg.vmult(z, b)
-    h.mg.connect_stages(None)
+    ms = h.mg.stage_times() / reps
+    h.mg.stage_timing(False)
     nl = len(N)
-    print("   level  n_dofs      pre    resid   restr   coarse  prol    post   [ms, eager+sync per stage]")
+    print(f"   stage times [ms per cycle, HIP events, sum = {ms.sum():.3f}]   to_mg {ms[7].sum():.3f}  to_global {ms[8].sum():.3f}")
+    print("   level  n_dofs      pre    resid   restr   coarse  prol    post")
     for lv in range(nl - 1, -1, -1):
-        row = [acc.get((s, lv), 0.0) / 3 * 1e3 for s in (0, 1, 2, 3, 4, 6)]
-        print(f"   {lv:3d} {N[lv]:10d} " + " ".join(f"{v:7.3f}" for v in row))
+        row = [ms[s_, lv] for s_ in (0, 1, 2, 3, 4, 6)]
+        if sum(row) > 0:
+            print(f"   {lv:3d} {N[lv]:10d} " + " ".join(f"{v:7.3f}" for v in row))
     it, res = m.solve_cg(h.fine_operator, h.mg, z, b, 1e-4)
     print(f"   CG iterations {it}, residual {res:.3e}", flush=True)

@@ -14,6 +14,9 @@ x, y, b = (op.initialize_dof_vector() for _ in range(3))
 x.from_host(np.random.default_rng(0).standard_normal(n)); b.from_host(np.random.default_rng(1).standard_normal(n))
 if mode == 0:
     for _ in range(3): op.vmult(y, x)
+elif mode in (4, 5):  # zero-start passes
+    ch = m.PreconditionChebyshev(op, 3, 20.0, 2)
+    for _ in range(3): ch.vmult(y, b)
 else:
     ch = m.PreconditionChebyshev(op, 3, 20.0, 2)
     for _ in range(3): ch.step(y, b)

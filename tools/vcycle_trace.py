@@ -1,0 +1,30 @@
+"""Run N V-cycles of one workload between two marker kernels, for `rocprofv3 --kernel-trace --output-format csv`:
+tools/vcycle_table.py then keeps only the dispatches between the markers, so that the per-kernel sums add up to the
+V-cycle time (no setup, no eigenvalue estimation, no collapse tabulation in the statistics).
+
+  rocprofv3 --kernel-trace --output-format csv -d gpurun_out/trace -o t -- python3 tools/vcycle_trace.py quadrant 8 4 [cycles]
+"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import dealii_multigrid_amd as m
+
+MARKER_N = 77777  # vec_set on a vector of this length = the marker dispatch
+
+geo, L, p = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+cycles = int(sys.argv[4]) if len(sys.argv) > 4 else 5
+mg_type = sys.argv[5] if len(sys.argv) > 5 else "HMG-global"
+ctx = m.Context(0)
+h = m.Hierarchy(ctx, geo, L, p, mg_type, coarse_solver="amg" if mg_type == "HMG-global" else "cg_with_chebyshev")
+b, z = h.fine_operator.initialize_dof_vector(), h.fine_operator.initialize_dof_vector()
+h.fine_operator.rhs(b)
+marker = m.Vector(ctx, MARKER_N)
+for _ in range(3):
+    h.mg.vmult(z, b)
+ctx.synchronize()
+marker.set(1.0)
+for _ in range(cycles):
+    h.mg.vmult(z, b)
+marker.set(2.0)
+ctx.synchronize()
+ms = h.mg.time_vcycles(z, b, cycles, False)
+print(f"{geo} L={L} p={p} {mg_type}: n_dofs={h.n_dofs} levels={[d.n_dofs for d in h.dofs]} cycles={cycles} eager {ms:.3f} ms/cycle", flush=True)
