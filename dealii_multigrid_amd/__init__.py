@@ -467,15 +467,26 @@ _STAGE_CB = C.CFUNCTYPE(None, C.c_int, C.c_int, C.c_uint, C.c_void_p)
 class PreconditionMG:
     """Multigrid<Vector> + PreconditionMG over MGTransferGlobalCoarsening."""
 
-    def __init__(self, ctx: Context, levels, transfers, smoothers, coarse_solver="direct"):
-        self.ctx, self.levels, self.transfers, self.smoothers = ctx, levels, transfers, smoothers
+    def __init__(self, ctx: Context, levels, transfers, smoothers, coarse_solver="direct", nested: "PreconditionMG" = None,
+                 n_cycles: int = 1):
+        """nested: geometric stand-in for the AMG coarse solvers on a large coarse level (an h-multigrid whose finest level
+        is levels[0]), applied n_cycles times per coarse solve; see mgamd.h"""
+        self.ctx, self.levels, self.transfers, self.smoothers, self.nested = ctx, levels, transfers, smoothers, nested
         n = len(levels)
         L = (C.c_void_p * n)(*[l._h for l in levels])
         T = (C.c_void_p * n)(*[(t._h if t is not None else None) for t in transfers])
         S = (C.c_void_p * n)(*[(s._h if s is not None else None) for s in smoothers])
         self._h = C.c_void_p()
-        _chk(_lib.mgamd_mg_create(ctx._h, n, L, T, S, coarse_solver.encode(), C.byref(self._h)))
+        if nested is None:
+            _chk(_lib.mgamd_mg_create(ctx._h, n, L, T, S, coarse_solver.encode(), C.byref(self._h)))
+        else:
+            _chk(_lib.mgamd_mg_create_nested(ctx._h, n, L, T, S, coarse_solver.encode(), nested._h, n_cycles, C.byref(self._h)))
         self._cb = None
+
+    def coarse_solver_used(self) -> str:
+        buf = C.create_string_buffer(32)
+        _chk(_lib.mgamd_mg_coarse_solver_used(self._h, buf))
+        return buf.value.decode()
 
     def vmult(self, z: Vector, r: Vector):
         _chk(_lib.mgamd_mg_vcycle(self._h, z._h, r._h))
@@ -520,12 +531,30 @@ def solve_cg(A: Operator, preconditioner, x: Vector, b: Vector, reltol=1e-4, abs
     return it.value, res.value
 
 
+AMG_COARSE_SOLVERS = ("amg", "cg_with_amg", "amg_petsc")
+
+
+class CoarseHierarchy:
+    """Geometric stand-in for the reference's AMG coarse solvers (mgamd.h: "gmg_vcycle"): the h-multigrid on the coarse
+    level of a PMG hierarchy (the lowest-degree space on the finest mesh); its finest level shares that level's objects."""
+
+    def __init__(self, ctx, tria, dofs0, op0, smoother0, smoother_degree, smoothing_range, eig_cg_n_iterations, number_type, max_brick):
+        self.trias = create_geometric_coarsening_sequence(tria)
+        p0 = dofs0.degree
+        self.dofs = [DoFs(t, p0, max_brick) for t in self.trias[:-1]] + [dofs0]
+        self.operators = [Operator(ctx, d, number_type) for d in self.dofs[:-1]] + [op0]
+        self.transfers = [None] + [MGTwoLevelTransfer(self.operators[l], self.operators[l - 1]) for l in range(1, len(self.dofs))]
+        self.smoothers = [PreconditionChebyshev(op, smoother_degree, smoothing_range, eig_cg_n_iterations) for op in self.operators[:-1]]
+        self.smoothers.append(smoother0)
+        self.mg = PreconditionMG(ctx, self.operators, self.transfers, self.smoothers, "amg")
+
+
 class Hierarchy:
     """What solve_with_global_coarsening builds (ref:multigrid_throughput.cc:1443-1666)."""
 
     def __init__(self, ctx: Context, geometry="quadrant", n_ref_global=3, degree=1, mg_type="HMG-global", n_ref_local=0,
                  smoother_degree=3, smoothing_range=20.0, eig_cg_n_iterations=20, coarse_solver="amg", number_type=F64,
-                 max_brick=-1):
+                 max_brick=-1, coarse_n_cycles=1):
         self.ctx = ctx
         fine = Triangulation(geometry, n_ref_global, n_ref_local)
         if mg_type == "HMG-global":
@@ -548,7 +577,13 @@ class Hierarchy:
         self.operators = [Operator(ctx, d, number_type) for d in self.dofs]
         self.transfers = [None] + [MGTwoLevelTransfer(self.operators[l], self.operators[l - 1]) for l in range(1, len(self.dofs))]
         self.smoothers = [PreconditionChebyshev(op, smoother_degree, smoothing_range, eig_cg_n_iterations) for op in self.operators]
-        self.mg = PreconditionMG(ctx, self.operators, self.transfers, self.smoothers, coarse_solver)
+        self.coarse = None
+        if coarse_solver in AMG_COARSE_SOLVERS and self.dofs[0].n_dofs > 4096:
+            # the AMG coarse solvers on a large coarse level (PMG): geometric stand-in, V-cycles of the h-multigrid on level 0
+            self.coarse = CoarseHierarchy(ctx, self.trias[0], self.dofs[0], self.operators[0], self.smoothers[0], smoother_degree,
+                                          smoothing_range, eig_cg_n_iterations, number_type, max_brick)
+        self.mg = PreconditionMG(ctx, self.operators, self.transfers, self.smoothers, coarse_solver,
+                                 self.coarse.mg if self.coarse else None, coarse_n_cycles)
         self.fine_operator = self.operators[-1] if number_type == F64 else Operator(ctx, self.dofs[-1], F64)
         self.n_dofs = self.dofs[-1].n_dofs
 

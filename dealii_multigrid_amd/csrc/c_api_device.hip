@@ -1,5 +1,6 @@
 // C ABI, device entry points (include/mgamd.h, section "Device runtime").
 #include "runtime.hpp"
+#include <cstdio>
 
 using namespace mgamd;
 
@@ -521,6 +522,48 @@ mgamd_mg_create(mgamd_ctx *ctx, unsigned n_levels, mgamd_level_op *const *levels
       throw;
     }
   *out = h;
+  MGAMD_CATCH
+}
+
+int
+mgamd_mg_create_nested(mgamd_ctx *ctx, unsigned n_levels, mgamd_level_op *const *levels, mgamd_transfer2 *const *transfers,
+                       mgamd_cheb *const *smoothers, const char *coarse_solver, mgamd_mg *coarse_mg, unsigned n_cycles, mgamd_mg **out)
+{
+  MGAMD_TRY
+  REQUIRE(ctx && levels && out && coarse_mg && n_levels > 0 && (n_levels == 1 || (transfers && smoothers)));
+  std::vector<LevelOperatorBase *> L(n_levels, nullptr);
+  std::vector<Transfer2Base *>     Tr(n_levels, nullptr);
+  std::vector<ChebyshevBase *>     Sm(n_levels, nullptr);
+  for (unsigned l = 0; l < n_levels; ++l)
+    {
+      REQUIRE(levels[l]);
+      L[l] = levels[l]->op.get();
+      if (transfers && transfers[l])
+        Tr[l] = transfers[l]->t.get();
+      if (smoothers && smoothers[l])
+        Sm[l] = smoothers[l]->c.get();
+    }
+  auto *h = new mgamd_mg;
+  try
+    {
+      h->mg.reset(make_multigrid(ctx->ctx.get(), n_levels, L.data(), Tr.data(), Sm.data(), coarse_solver ? coarse_solver : "amg",
+                                 coarse_mg->mg.get(), n_cycles));
+    }
+  catch (...)
+    {
+      delete h;
+      throw;
+    }
+  *out = h;
+  MGAMD_CATCH
+}
+
+int
+mgamd_mg_coarse_solver_used(const mgamd_mg *mg, char name[32])
+{
+  MGAMD_TRY
+  REQUIRE(mg && name);
+  std::snprintf(name, 32, "%s", mg->mg->coarse_used.c_str());
   MGAMD_CATCH
 }
 

@@ -374,8 +374,11 @@ namespace mgamd
   {
   public:
     using StageSlot = std::function<void(bool /*start*/, unsigned /*level*/)>;
+    // coarse_mg: the geometric stand-in for the AMG coarse solvers on a large coarse level (an h-multigrid whose finest level
+    // is mg_matrices[0]), applied n_cycles times per coarse solve
     PreconditionMG(const Context &ctx, const std::vector<Operator> &mg_matrices, const std::vector<MGTwoLevelTransfer> &transfers,
-                   const std::vector<PreconditionChebyshev> &smoothers, const std::string &coarse_grid_solver_type)
+                   const std::vector<PreconditionChebyshev> &smoothers, const std::string &coarse_grid_solver_type,
+                   const PreconditionMG *coarse_mg = nullptr, unsigned n_cycles = 1)
     {
       const unsigned                 n = mg_matrices.size();
       std::vector<mgamd_level_op *>  L(n);
@@ -389,9 +392,43 @@ namespace mgamd
             T[l] = transfers[l].get();
         }
       mgamd_mg *m = nullptr;
-      check(mgamd_mg_create(ctx.get(), n, L.data(), T.data(), S.data(), coarse_grid_solver_type.c_str(), &m));
+      if (coarse_mg)
+        {
+          check(mgamd_mg_create_nested(ctx.get(), n, L.data(), T.data(), S.data(), coarse_grid_solver_type.c_str(), coarse_mg->get(),
+                                       n_cycles, &m));
+          nested = coarse_mg->h; // keep the nested hierarchy's handle alive
+        }
+      else
+        check(mgamd_mg_create(ctx.get(), n, L.data(), T.data(), S.data(), coarse_grid_solver_type.c_str(), &m));
       h.reset(m, mgamd_mg_destroy);
       slots.resize(9);
+      n_levels = n;
+    }
+    // the coarse solver that actually runs: "direct" | "cg" | "cg_with_chebyshev" | "gmg_vcycle" (see mgamd.h)
+    std::string
+    coarse_solver_used() const
+    {
+      char name[32];
+      check(mgamd_mg_coarse_solver_used(h.get(), name));
+      return name;
+    }
+    // stage times of the UNCHANGED cycle from HIP events (no host synchronisation inside the cycle): enable, run solves,
+    // then read_stage_times() adds seconds to t[stage][level] (stages as in the connect_* slots, 7/8 = transfer to mg/global)
+    void
+    enable_stage_timing(bool on) const
+    {
+      check(mgamd_mg_stage_timing(h.get(), on ? 1 : 0));
+    }
+    void
+    read_stage_times(std::vector<std::vector<double>> &t) const
+    {
+      std::vector<double> ms(9 * (size_t)n_levels, 0.0);
+      uint64_t            n = 0;
+      check(mgamd_mg_stage_times(h.get(), ms.data(), n_levels, &n));
+      t.assign(9, std::vector<double>(n_levels, 0.0));
+      for (unsigned st = 0; st < 9; ++st)
+        for (unsigned l = 0; l < n_levels; ++l)
+          t[st][l] = ms[st * (size_t)n_levels + l] * 1e-3;
     }
     void
     vmult(Vector &dst, const Vector &src) const
@@ -471,8 +508,9 @@ namespace mgamd
       if (stage >= 0 && stage < (int)self->slots.size() && self->slots[stage])
         self->slots[stage](start != 0, level);
     }
-    std::shared_ptr<mgamd_mg> h;
+    std::shared_ptr<mgamd_mg> h, nested;
     std::vector<StageSlot>    slots;
+    unsigned                  n_levels = 0;
   };
 
   class ReductionControl

@@ -1522,11 +1522,28 @@ namespace mgamd
     hipGraphExec_t                   graph_exec = nullptr;
     const void                      *graph_z = nullptr, *graph_r = nullptr;
 
-    MultigridT(Ctx *c, unsigned n_levels, LevelOperatorBase *const *levels, Transfer2Base *const *transfers,
-               ChebyshevBase *const *smoothers, const std::string &coarse)
+    MultigridBase *nested   = nullptr; // coarse solver "gmg_vcycle"
+    unsigned       n_cycles = 1;
+
+    LevelOperatorBase *
+    finest_operator() const override
     {
-      ctx = c;
-      nl  = n_levels;
+      return ops[nl - 1];
+    }
+    void
+    vcycle_level_raw(void *z, const void *r) override
+    {
+      vcycle_raw<T>(static_cast<T *>(z), static_cast<const T *>(r));
+    }
+
+    MultigridT(Ctx *c, unsigned n_levels, LevelOperatorBase *const *levels, Transfer2Base *const *transfers,
+               ChebyshevBase *const *smoothers, const std::string &coarse, MultigridBase *nested_mg, unsigned nested_cycles)
+    {
+      ctx         = c;
+      nl          = n_levels;
+      number_type = (int)sizeof(T);
+      nested      = nested_mg;
+      n_cycles    = std::max(1u, nested_cycles);
       if (nl < 1)
         throw std::invalid_argument("multigrid: need at least one level");
       for (unsigned l = 0; l < nl; ++l)
@@ -1576,10 +1593,36 @@ namespace mgamd
           sview[l] = S[l]->p;
           tview[l] = Tb[l]->p;
         }
+      // ONE policy for the reference's Trilinos/PETSc choices ("amg", "cg_with_amg", "amg_petsc"), which cannot exist here:
+      // on a coarse level of <= 4096 DoFs (global coarsening: one cell) any AMG degenerates to an exact solve -> "direct";
+      // on larger coarse levels (PMG, HPMG with MinLevel) the caller must supply the geometric stand-in (`nested`: V-cycles
+      // of an h-multigrid on that level) -> "gmg_vcycle"; otherwise the request is refused.  Never a silent substitution:
+      // coarse_used names what runs (harness table column / bench JSON).
       coarse_type = coarse;
-      if (coarse == "amg" || coarse == "cg_with_amg" || coarse == "amg_petsc")
-        coarse_type = "direct"; // 1-cell coarse level: ML/BoomerAMG degenerate to a direct solve
-      if (coarse_type == "direct")
+      const bool amg_like = coarse == "amg" || coarse == "cg_with_amg" || coarse == "amg_petsc";
+      if (nested)
+        {
+          if (!amg_like && coarse != "gmg_vcycle")
+            throw std::invalid_argument("multigrid: a nested multigrid is the stand-in for the AMG coarse solvers only");
+          if (nested->number_type != (int)sizeof(T) || nested->finest_operator() != ops[0])
+            throw std::invalid_argument("multigrid: the nested multigrid must end on this hierarchy's level 0 (same number type)");
+          coarse_type = "gmg_vcycle";
+        }
+      else if (amg_like)
+        {
+          if (ops[0]->n_dofs() > 4096)
+            throw std::runtime_error("CoarseGridSolverType '" + coarse + "' on a coarse level of " + std::to_string(ops[0]->n_dofs()) +
+                                     " DoFs needs Trilinos/PETSc: not implemented here; use cg, cg_with_chebyshev, or the geometric "
+                                     "stand-in (nested multigrid, coarse solver gmg_vcycle)");
+          coarse_type = "direct";
+        }
+      coarse_used = coarse_type;
+      if (coarse_type == "gmg_vcycle")
+        {
+          if (n_cycles > 1)
+            cg_r.alloc(ops[0]->n_dofs()), cg_z.alloc(ops[0]->n_dofs());
+        }
+      else if (coarse_type == "direct")
         setup_direct();
       else if (coarse_type == "cg" || coarse_type == "cg_with_chebyshev")
         {
@@ -1791,6 +1834,17 @@ namespace mgamd
           if (coarse_type == "direct")
             hipLaunchKernelGGL(dense_matvec_kernel<T>, (int)std::min<size_t>(n, 1024), 256, 0, ctx->stream, coarse_inv.p, dptr[0],
                                S[0]->p, (int)n);
+          else if (coarse_type == "gmg_vcycle")
+            {
+              // x = V(b); then n_cycles - 1 corrections x += V(b - A x)   (AMG applied n_cycles times, ref CoarseSolverNCycles)
+              nested->vcycle_level_raw(S[0]->p, dptr[0]);
+              for (unsigned c = 1; c < n_cycles; ++c)
+                {
+                  ops[0]->residual_raw(cg_r.p, dptr[0], S[0]->p);
+                  nested->vcycle_level_raw(cg_z.p, cg_r.p);
+                  hipLaunchKernelGGL(vec_sadd_kernel<T>, grid_for(n), 256, 0, ctx->stream, S[0]->p, T(1), T(1), cg_z.p, n);
+                }
+            }
           else
             coarse_cg(S[0]->p, dptr[0], coarse_type == "cg_with_chebyshev");
           sol[0] = S[0]->p;
@@ -1894,7 +1948,7 @@ namespace mgamd
         return 0.0;
       if (cb || stage_timing)
         throw std::invalid_argument("time_vcycles: remove the stage callback / stage timing first");
-      const bool graphable = coarse_type == "direct" && !ops[nl - 1]->comm;
+      const bool graphable = coarse_type == "direct" && !ops[nl - 1]->comm; // (nested cycles are not captured)
       vcycle(z, r); // warm-up: sets kernel attributes, touches memory
       ctx->sync();
       if (use_graph && graphable && (!graph_exec || graph_z != z.data || graph_r != r.data))
@@ -1950,13 +2004,13 @@ namespace mgamd
 
   MultigridBase *
   make_multigrid(Ctx *ctx, unsigned n_levels, LevelOperatorBase *const *levels, Transfer2Base *const *transfers,
-                 ChebyshevBase *const *smoothers, const std::string &coarse_solver)
+                 ChebyshevBase *const *smoothers, const std::string &coarse_solver, MultigridBase *nested, unsigned n_cycles)
   {
     if (!n_levels || !levels || !levels[0])
       throw std::invalid_argument("multigrid: no levels");
     if (levels[0]->type == MGAMD_F64)
-      return new MultigridT<double>(ctx, n_levels, levels, transfers, smoothers, coarse_solver);
-    return new MultigridT<float>(ctx, n_levels, levels, transfers, smoothers, coarse_solver);
+      return new MultigridT<double>(ctx, n_levels, levels, transfers, smoothers, coarse_solver, nested, n_cycles);
+    return new MultigridT<float>(ctx, n_levels, levels, transfers, smoothers, coarse_solver, nested, n_cycles);
   }
 
   // ------------------------------------------------------------------------------------------

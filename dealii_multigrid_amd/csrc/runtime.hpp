@@ -232,6 +232,14 @@ namespace mgamd
     time_vcycles(mgamd_vec &z, const mgamd_vec &r, unsigned n, bool use_graph) = 0;
     virtual unsigned
     n_levels() const = 0;
+    // the coarse solver actually in use ("direct", "cg", "cg_with_chebyshev", "gmg_vcycle")
+    std::string coarse_used;
+    int         number_type = MGAMD_F64;
+    virtual LevelOperatorBase *
+    finest_operator() const = 0;
+    // z = V-cycle(r) on raw device pointers of the LEVEL number type (nested use)
+    virtual void
+    vcycle_level_raw(void *z, const void *r) = 0;
 
     // Stage times without host synchronisation: a HIP event pair is recorded on the stream around every stage of the
     // UNCHANGED cycle (same code path as an un-instrumented cycle, collapsed coarse levels included) and resolved when read.
@@ -284,9 +292,12 @@ namespace mgamd
   make_chebyshev(LevelOperatorBase *op, unsigned degree, double smoothing_range, unsigned eig_cg_n_iterations);
   Transfer2Base *
   make_transfer2(LevelOperatorBase *fine, LevelOperatorBase *coarse);
+  // nested != nullptr: the coarse problem is handed to `n_cycles` V-cycles of another multigrid whose finest level is
+  // levels[0] (the geometric stand-in for the reference's Trilinos/PETSc AMG coarse solvers on large coarse levels)
   MultigridBase *
   make_multigrid(Ctx *ctx, unsigned n_levels, LevelOperatorBase *const *levels, Transfer2Base *const *transfers,
-                 ChebyshevBase *const *smoothers, const std::string &coarse_solver);
+                 ChebyshevBase *const *smoothers, const std::string &coarse_solver, MultigridBase *nested = nullptr,
+                 unsigned n_cycles = 1);
   void
   solve_cg(LevelOperatorBase &A, MultigridBase *M, mgamd_vec &x, const mgamd_vec &b, double reltol, double abstol, unsigned maxiter,
            unsigned &n_iterations, double &residual);

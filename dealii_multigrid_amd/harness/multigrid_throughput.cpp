@@ -180,8 +180,13 @@ public:
   add_value(const std::string &key, const V &value, bool scientific = false)
   {
     std::ostringstream os;
-    if (scientific)
-      os << std::scientific << std::setprecision(4) << (double)value;
+    if constexpr (std::is_arithmetic<V>::value)
+      {
+        if (scientific)
+          os << std::scientific << std::setprecision(4) << (double)value;
+        else
+          os << value;
+      }
     else
       os << value;
     if (std::find(order.begin(), order.end(), key) == order.end())
@@ -319,16 +324,39 @@ run(const Context &ctx, const RunParameters &params, ConvergenceTable &table)
   for (unsigned l = 0; l < n_levels; ++l)
     smoothers[l].initialize(operators[l], sd);
 
-  // coarse solver: the Trilinos/PETSc AMG options degenerate to a direct solve on a one-cell coarse level; on
-  // larger coarse levels (PMG, MinLevel) fall back to the reference's Trilinos-free "cg_with_chebyshev"
-  std::string coarse = params.mg_data.coarse_solver.type;
-  if ((coarse == "amg" || coarse == "cg_with_amg" || coarse == "amg_petsc") && dof_handlers[0].n_dofs() > 4096)
+  // coarse solver (library policy, include/mgamd.h): the Trilinos/PETSc AMG options are an exact solve on the one-cell coarse
+  // level of global coarsening; on a large coarse level (PMG, MinLevel) they are replaced by the geometric stand-in -- V-cycles
+  // of the h-multigrid on that level -- and the table says so in its `coarse_solver` column
+  const std::string coarse = params.mg_data.coarse_solver.type;
+  const bool amg_like      = coarse == "amg" || coarse == "cg_with_amg" || coarse == "amg_petsc";
+  std::vector<DoFHandler>            c_dof_handlers;
+  std::vector<Operator>              c_operators;
+  std::vector<MGTwoLevelTransfer>    c_transfers;
+  std::vector<PreconditionChebyshev> c_smoothers;
+  std::unique_ptr<PreconditionMG>    coarse_mg;
+  if (amg_like && dof_handlers[0].n_dofs() > 4096)
     {
-      std::cout << "note: CoarseGridSolverType '" << coarse << "' needs Trilinos/PETSc; using cg_with_chebyshev on the "
-                << dof_handlers[0].n_dofs() << "-DoF coarse level" << std::endl;
-      coarse = "cg_with_chebyshev";
+      const auto c_trias = create_geometric_coarsening_sequence(triangulations[0]);
+      const unsigned nc  = c_trias.size();
+      c_operators.resize(nc);
+      c_transfers.resize(nc);
+      c_smoothers.resize(nc);
+      for (unsigned l = 0; l + 1 < nc; ++l)
+        c_dof_handlers.emplace_back(c_trias[l], degrees[0]);
+      for (unsigned l = 0; l + 1 < nc; ++l)
+        c_operators[l].reinit(ctx, c_dof_handlers[l], level_number_type);
+      c_operators[nc - 1] = operators[0];
+      for (unsigned l = 1; l < nc; ++l)
+        c_transfers[l].reinit(c_operators[l], c_operators[l - 1]);
+      for (unsigned l = 0; l + 1 < nc; ++l)
+        c_smoothers[l].initialize(c_operators[l], sd);
+      c_smoothers[nc - 1] = smoothers[0];
+      coarse_mg           = std::make_unique<PreconditionMG>(ctx, c_operators, c_transfers, c_smoothers, "amg");
+      std::cout << "note: CoarseGridSolverType '" << coarse << "' on the " << dof_handlers[0].n_dofs()
+                << "-DoF coarse level: Trilinos/PETSc are not available, using " << params.mg_data.coarse_solver.n_cycles
+                << " V-cycle(s) of the geometric multigrid on that level (gmg_vcycle)" << std::endl;
     }
-  PreconditionMG preconditioner(ctx, operators, transfers, smoothers, coarse);
+  PreconditionMG preconditioner(ctx, operators, transfers, smoothers, coarse, coarse_mg.get(), params.mg_data.coarse_solver.n_cycles);
 
   // fine (outer, double) operator, right-hand side (ref:multigrid_throughput.cc:2262-2324)
   Operator op;
@@ -368,42 +396,14 @@ run(const Context &ctx, const RunParameters &params, ConvergenceTable &table)
   solution = 0.0;
   SolverCG(solver_control).solve(op, solution, rhs, preconditioner); // warm-up
 
+  // Stage times: the reference connects host timers to Multigrid's signals (ref:multigrid_throughput.cc:1150-1234).  Here the
+  // stages are bracketed by HIP events on the stream of the UNCHANGED cycle (no host synchronisation, collapsed coarse levels
+  // included) and read after each solve, so `time`, `throughput` and the stage columns describe the same run.
   const unsigned n_repetitions = params.mg_data.n_repetitions;
-  unsigned       counter       = 0;
-  using TP                     = std::chrono::time_point<std::chrono::system_clock>;
-  std::vector<std::vector<std::vector<std::pair<double, TP>>>> all_mg_timers(
-    n_repetitions, std::vector<std::vector<std::pair<double, TP>>>(n_levels, std::vector<std::pair<double, TP>>(7)));
-  std::vector<std::vector<std::pair<double, TP>>> all_mg_precon_timers(n_repetitions, std::vector<std::pair<double, TP>>(2));
-  auto mg_timer = [&](unsigned i) {
-    return [i, &all_mg_timers, &counter](bool flag, unsigned level) {
-      auto &t = all_mg_timers[counter][level][i];
-      if (flag)
-        t.second = std::chrono::system_clock::now();
-      else
-        t.first += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::system_clock::now() - t.second).count() / 1e9;
-    };
-  };
-  auto precon_timer = [&](unsigned i) {
-    return [i, &all_mg_precon_timers, &counter](bool flag) {
-      auto &t = all_mg_precon_timers[counter][i];
-      if (flag)
-        t.second = std::chrono::system_clock::now();
-      else
-        t.first += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::system_clock::now() - t.second).count() / 1e9;
-    };
-  };
-  preconditioner.connect_pre_smoother_step(mg_timer(0));
-  preconditioner.connect_residual_step(mg_timer(1));
-  preconditioner.connect_restriction(mg_timer(2));
-  preconditioner.connect_coarse_solve(mg_timer(3));
-  preconditioner.connect_prolongation(mg_timer(4));
-  preconditioner.connect_edge_prolongation(mg_timer(5));
-  preconditioner.connect_post_smoother_step(mg_timer(6));
-  preconditioner.connect_transfer_to_mg(precon_timer(0));
-  preconditioner.connect_transfer_to_global(precon_timer(1));
-
-  std::vector<double> times(n_repetitions);
-  for (; counter < n_repetitions; ++counter)
+  std::vector<std::vector<std::vector<double>>> all_stage_times(n_repetitions); // [repetition][stage 0..8][level], seconds
+  std::vector<double>                           times(n_repetitions);
+  preconditioner.enable_stage_timing(true);
+  for (unsigned counter = 0; counter < n_repetitions; ++counter)
     {
       ctx.synchronize(); // MPI_Barrier
       double time = 0.0;
@@ -413,17 +413,16 @@ run(const Context &ctx, const RunParameters &params, ConvergenceTable &table)
         SolverCG(solver_control).solve(op, solution, rhs, preconditioner);
       }
       times[counter] = time;
+      preconditioner.read_stage_times(all_stage_times[counter]);
     }
-  preconditioner.disconnect_all();
+  preconditioner.enable_stage_timing(false);
   const unsigned min_index = std::min_element(times.begin(), times.end()) - times.begin();
   const double   time      = times[min_index];
-  const auto    &mg_timers = all_mg_timers[min_index];
+  const auto    &st        = all_stage_times[min_index];
   double         time_cg   = time;
-  for (const auto &lv : mg_timers)
-    for (const auto &st : lv)
-      time_cg -= st.first;
-  for (const auto &st : all_mg_precon_timers[min_index])
-    time_cg -= st.first;
+  for (const auto &stage : st)
+    for (const double v : stage)
+      time_cg -= v;
   const unsigned its = std::max(1u, solver_control.last_step());
   table.add_value("n_levels", n_levels);
   table.add_value("n_iterations", solver_control.last_step());
@@ -436,15 +435,23 @@ run(const Context &ctx, const RunParameters &params, ConvergenceTable &table)
     {
       double s = 0;
       for (unsigned l = 0; l < n_levels; ++l)
-        s += mg_timers[l][j].first / its;
+        s += st[j][l] / its;
       t_v += s;
       table.add_value(stage_cols[j], s, true);
     }
-  table.add_value("time_to_mg", all_mg_precon_timers[min_index][0].first / its, true);
-  table.add_value("time_to_global", all_mg_precon_timers[min_index][1].first / its, true);
-  t_v += (all_mg_precon_timers[min_index][0].first + all_mg_precon_timers[min_index][1].first) / its;
-  // this project's unit: DoF/s per V-cycle = n_dofs / (sum of the nine stage columns)
+  double t_to_mg = 0, t_to_global = 0;
+  for (unsigned l = 0; l < n_levels; ++l)
+    {
+      t_to_mg += st[7][l] / its;
+      t_to_global += st[8][l] / its;
+    }
+  table.add_value("time_to_mg", t_to_mg, true);
+  table.add_value("time_to_global", t_to_global, true);
+  t_v += t_to_mg + t_to_global;
+  // this project's additions (after the reference's columns): DoF/s per V-cycle = n_dofs / (sum of the nine stage columns)
+  //  and the coarse solver that actually ran
   table.add_value("dofs_per_s_per_vcycle", (double)rhs.size() / t_v, true);
+  table.add_value("coarse_solver", preconditioner.coarse_solver_used());
 
   if (params.verbose)
     {
@@ -453,7 +460,7 @@ run(const Context &ctx, const RunParameters &params, ConvergenceTable &table)
         {
           std::cout << "  level " << l << ":";
           for (unsigned j = 0; j < 7; ++j)
-            std::cout << " " << std::scientific << std::setprecision(3) << mg_timers[l][j].first / its;
+            std::cout << " " << std::scientific << std::setprecision(3) << st[j][l] / its;
           std::cout << std::endl;
         }
     }

@@ -230,6 +230,17 @@ int mgamd_transfer2_restrict_and_add(mgamd_transfer2 *t, mgamd_vec *dst_coarse, 
  * Trilinos/PETSc AMG choices map to "direct"). */
 int mgamd_mg_create(mgamd_ctx *ctx, unsigned n_levels, mgamd_level_op *const *levels, mgamd_transfer2 *const *transfers,
                     mgamd_cheb *const *smoothers, const char *coarse_solver, mgamd_mg **out);
+/* The reference's AMG coarse solvers ("amg": one ML V-cycle applied CoarseSolverNCycles times, "cg_with_amg", "amg_petsc":
+ * ref:multigrid_throughput.cc:945-1077) need Trilinos/PETSc.  Policy of this library (one place, never silent):
+ *   - coarse level of <= 4096 DoFs (global coarsening ends on one cell): an exact solve, "direct";
+ *   - larger coarse levels (PMG: the p = 1 space on the finest mesh): mgamd_mg_create refuses; mgamd_mg_create_nested takes
+ *     the geometric stand-in: `coarse_mg`, an h-multigrid whose finest level IS levels[0], applied n_cycles times
+ *     (x = V(b), x += V(b - A x) ...), reported as "gmg_vcycle".
+ * mgamd_mg_coarse_solver_used returns what runs: "direct" | "cg" | "cg_with_chebyshev" | "gmg_vcycle". */
+int mgamd_mg_create_nested(mgamd_ctx *ctx, unsigned n_levels, mgamd_level_op *const *levels, mgamd_transfer2 *const *transfers,
+                           mgamd_cheb *const *smoothers, const char *coarse_solver, mgamd_mg *coarse_mg, unsigned n_cycles,
+                           mgamd_mg **out);
+int mgamd_mg_coarse_solver_used(const mgamd_mg *mg, char name[32]);
 int mgamd_mg_destroy(mgamd_mg *mg);
 /* PreconditionMG::vmult: z = V-cycle(r)  (ref:multigrid_throughput.cc:1132-1133) -- the metric's unit of work.
  * z and r are vectors of the finest level's outer number type (double). */

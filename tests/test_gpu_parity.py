@@ -384,3 +384,42 @@ def test_event_stage_timing(mgamd, ctx):
     assert len(cs) == 1 and ms[0, : cs[0] + 1].sum() == 0  # one coarse "solve"; nothing is smoothed at or below it
     t = h.mg.time_vcycles(vz, vr, 5, False)
     assert 0.5 * t < ms.sum() < 2.0 * t
+
+
+def test_amg_coarse_solver_policy(mgamd, oracle, ctx):
+    """The reference's AMG coarse solvers need Trilinos/PETSc.  One policy (mgamd.h): exact solve on a coarse level of
+    <= 4096 DoFs; on a larger one mgamd_mg_create refuses and the hierarchy supplies the geometric stand-in (V-cycles of the
+    h-multigrid on that level, "gmg_vcycle").  With one cycle PMG + stand-in IS the HPMG V-cycle: checked against the
+    oracle's HPMG hierarchy (9,763-DoF coarse level)."""
+    h = mgamd.Hierarchy(ctx, "annulus", 6, 2, "PMG", coarse_solver="amg", max_brick=0)
+    assert h.dofs[0].n_dofs == 9763 and h.mg.coarse_solver_used() == "gmg_vcycle"
+    with pytest.raises(mgamd.MgamdError, match="Trilinos/PETSc"):
+        mgamd.PreconditionMG(ctx, h.operators, h.transfers, h.smoothers, "amg")
+    assert mgamd.Hierarchy(ctx, "annulus", 5, 2, "PMG", coarse_solver="amg").mg.coarse_solver_used() == "direct"  # 1,965 DoFs
+    keys = [d.keys() for d in h.coarse.dofs] + [d.keys() for d in h.dofs[1:]]
+    levels, P = oracle.build_hierarchy("annulus", 6, 2, "HPMG", numbering_keys=keys)
+    mg = oracle.Multigrid(levels, P, 3, coarse="direct")
+    n = levels[-1].n
+    r = np.random.default_rng(12).standard_normal(n)
+    vr, vz = mgamd.Vector(ctx, n).from_host(r), mgamd.Vector(ctx, n)
+    h.mg.vmult(vz, vr)
+    assert rel_err(vz.to_host(), mg.vcycle(r)) < 1e-11
+    xref, itref, hist = oracle.pcg(levels[-1].A, levels[-1].rhs_constant, mg.vcycle, 1e-4)
+    b, x = h.fine_operator.initialize_dof_vector(), h.fine_operator.initialize_dof_vector()
+    h.fine_operator.rhs(b)
+    it, res = mgamd.solve_cg(h.fine_operator, h.mg, x, b, 1e-4)
+    assert it == itref and rel_err(x.to_host(), xref) < TOL_SOL
+    # CoarseSolverNCycles = 2 on a one-level hierarchy: the "V-cycle" is the coarse solve x = V(b) + V(b - A V(b))
+    h2 = mgamd.Hierarchy(ctx, "annulus", 6, 1, "PMG", coarse_solver="amg", max_brick=0, coarse_n_cycles=2)
+    assert len(h2.dofs) == 1 and h2.mg.coarse_solver_used() == "gmg_vcycle"
+    n = h2.n_dofs
+    bb = np.random.default_rng(13).standard_normal(n)
+    bb[h2.dofs[0].info.n_interior + h2.dofs[0].info.n_tail:] = 0.0
+    vb, v1, v2, vt, vz = (mgamd.Vector(ctx, n) for _ in range(5))
+    vb.from_host(bb)
+    h2.mg.vmult(vz, vb)
+    h2.coarse.mg.vmult(v1, vb)
+    h2.operators[0].vmult(vt, v1)
+    vt.sadd(-1.0, 1.0, vb)  # b - A x1
+    h2.coarse.mg.vmult(v2, vt)
+    assert rel_err(vz.to_host(), v1.to_host() + v2.to_host()) < 1e-12

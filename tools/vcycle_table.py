@@ -8,6 +8,10 @@ from collections import defaultdict
 
 path, cycles = sys.argv[1], int(sys.argv[2])
 rows = list(csv.DictReader(open(path)))
+if rows and "Grid_Size" not in rows[0]:  # kernel-trace CSV: per-dimension columns
+    for r in rows:
+        r["Grid_Size"] = int(r["Grid_Size_X"]) * int(r.get("Grid_Size_Y", 1) or 1) * int(r.get("Grid_Size_Z", 1) or 1)
+        r["Workgroup_Size"] = int(r["Workgroup_Size_X"]) * int(r.get("Workgroup_Size_Y", 1) or 1) * int(r.get("Workgroup_Size_Z", 1) or 1)
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 mark = [i for i, r in enumerate(rows) if "vec_set_kernel" in r["Kernel_Name"] and int(r["Grid_Size"]) == 304 * 256]
 assert len(mark) >= 2, f"markers not found ({len(mark)})"
