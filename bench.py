@@ -3,22 +3,29 @@
 
 A "step" is one application of PreconditionMG::vmult (copy_to_mg + V-cycle + copy_from_mg,
 ref:multigrid_throughput.cc:1132-1133) on the finest level of the workload, with the right-hand side
-already resident in HBM.  Workload (config.workload): the configuration the metric is quoted on,
-BASELINE.json configs[2]: 3D octant (GeometryType "quadrant"), global coarsening, p = 4, FP64,
-SmootherDegree 3 -- synthetic data (f == 1, zero Dirichlet), no dataset.  The p = 1 octant number that
-north_star also asks for is reported in the same line under "also".
+already resident in HBM.  Workloads (config.workload):
+
+  octant_p4 (default)  BASELINE.json configs[2]: 3D octant (GeometryType "quadrant"), global coarsening, p = 4, FP64,
+                       SmootherDegree 3 -- the configuration the metric is quoted on.  At N = 1 the line also carries, under
+                       "also", the octant p = 1 number north_star asks for and p = 1 on a uniform mesh that fills the GPU
+                       (BASELINE.json configs[1]).
+  pmg_annulus          BASELINE.json configs[4]: polynomial global coarsening p = 4 -> 2 -> 1 on the annulus; the p = 1
+                       coarse level is solved by CG preconditioned with its Chebyshev smoother (ref:multigrid_throughput.cc:922-944).
 
   python bench.py --gpus N --steps K --warmup W
   (N > 1: launched by torch.distributed.run, one rank per GPU.  The SAME global problem is sharded by spatial domain
    decomposition: every rank owns a Morton chunk of the octree, shared DoFs are exchanged with grouped RCCL
    send/recv over xGMI, the replicated coarse levels take one RCCL all-reduce -> "scaling": "strong",
-   value = global n_dofs / max-over-ranks time; see DESIGN.md section 7.  `--mode replicas` runs N independent copies.)
+   value = global n_dofs / max-over-ranks time; see DESIGN.md section 7.  `--mode replicas` runs N independent copies.
+   A sharded run that fails on any rank ends the job with a non-zero exit code: there is no in-process fallback.)
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0.  Synthetic data (f == 1, zero Dirichlet), no dataset.
 """
 import argparse
+import glob
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -26,22 +33,29 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+WORKLOADS = {
+    # name: (geometry, NRefGlobal default, degree, Type, coarse solver, BASELINE.json config)
+    "octant_p4": ("quadrant", 8, 4, "HMG-global", "amg", "configs[2]"),
+    "pmg_annulus": ("annulus", 8, 4, "PMG", "cg_with_chebyshev", "configs[4]"),
+}
 
 
 def algorithmic_bytes_per_vcycle(n_dofs_per_level, k=3, word=8):
     """s * [ (10k+3) * sum_{l>=1} N_l + 2 * sum_{l<L} N_l ]  (the reference algorithm's compulsory
     vector traffic with x_1 of the zero-start smoother stored; the implementation recomputes x_1 = D^-1 b / theta inside
-    the first two operator passes and moves 5 words per DoF and level fewer)."""
+    the first two operator passes and moves 5 words per DoF and level fewer).  Level 0 belongs to the
+    coarse solver (PMG: the p = 1 level), as in SURVEY's table."""
     N = n_dofs_per_level
     return word * ((10 * k + 3) * sum(N[1:]) + 2 * sum(N[:-1]))
 
 
-def run_workload(m, ctx, geometry, n_ref, degree, steps, warmup, barrier, sync, profile, comm=None):
+def run_workload(m, ctx, geometry, n_ref, degree, mg_type, coarse, steps, warmup, barrier, sync, profile, comm=None, details=False):
     t0 = time.time()
     if comm is None:
-        h = m.Hierarchy(ctx, geometry, n_ref, degree, "HMG-global", smoother_degree=3, coarse_solver="amg", number_type=m.F64)
+        h = m.Hierarchy(ctx, geometry, n_ref, degree, mg_type, smoother_degree=3, coarse_solver=coarse, number_type=m.F64)
     else:
-        h = m.DistributedHierarchy(ctx, comm, geometry, n_ref, degree, smoother_degree=3, coarse_solver="amg", number_type=m.F64)
+        h = m.DistributedHierarchy(ctx, comm, geometry, n_ref, degree, mg_type=mg_type, smoother_degree=3, coarse_solver=coarse,
+                                   number_type=m.F64)
     b, z = h.fine_operator.initialize_dof_vector(), h.fine_operator.initialize_dof_vector()
     h.fine_operator.rhs(b)
     ctx.synchronize()
@@ -68,40 +82,112 @@ def run_workload(m, ctx, geometry, n_ref, degree, steps, warmup, barrier, sync, 
     if comm is None:
         N = [d.n_dofs for d in h.dofs]
     else:  # global level sizes: owned DoFs summed over the ranks (replicated levels are complete on every rank)
-        N = [int(round(comm.allreduce_sum(ctx, float(op.n_owned())))) if l >= h.partition.root_level else h.dofs[l].n_dofs
+        N = [int(round(comm.allreduce_sum(ctx, float(op.n_owned())))) if h.distributed[l] else h.dofs[l].n_dofs
              for l, op in enumerate(h.operators)]
     res = dict(n_dofs=h.n_dofs, n_cells=h.trias[-1].n_cells, n_levels=len(N), level_dofs=N, elapsed=elapsed, setup_s=setup_s,
-               bytes_per_vcycle=algorithmic_bytes_per_vcycle(N), groups=h.dofs[-1].groups(), prof=prof)
+               bytes_per_vcycle=algorithmic_bytes_per_vcycle(N), groups=h.dofs[-1].groups(), prof=prof,
+               coarse_solver=h.mg.coarse_solver_used())
     if comm is not None:
         info = h.dofs[-1].info
         res["halo"] = dict(root_level=h.partition.root_level, peers=info.n_peers, halo_send_entries=info.n_halo_send, n_local=h.n_local)
-    # reference protocol for context: CG solve to reltol 1e-4 (ref:multigrid_throughput.cc:1238-1254)
+    if details and comm is None:
+        # (a) the same cycle with the tabulated coarse levels switched off
+        lc = h.mg.set_collapse(False)
+        res["collapse_level"] = lc
+        res["collapse_level_dofs"] = N[lc] if lc else 0
+        res["ms_no_collapse"] = h.mg.time_vcycles(z, b, max(steps // 2, 3), False)
+        h.mg.set_collapse(True)
+        # (b) per-level x per-stage times of the unchanged cycle (HIP events, no host synchronisation)
+        reps = max(steps // 4, 3)
+        h.mg.stage_timing(True)
+        for _ in range(reps):
+            h.mg.vmult(z, b)
+        ms = h.mg.stage_times() / reps
+        h.mg.stage_timing(False)
+        L = len(N) - 1
+        k = 3
+        res["stage_ms_finest"] = {name: float(ms[s, L]) for s, name in ((0, "pre"), (1, "residual"), (2, "restrict"), (4, "prolongate"), (6, "post"))}
+        res["stage_ms_total"] = float(ms.sum())
+        res["stage_ms_per_level"] = [float(ms[:, l].sum()) for l in range(len(N))]
+        # post-smoothing on the finest level: k operator passes moving 4 + 5 (k - 1) words per DoF, ALL kernels of the passes
+        # (bricks, small slots, tail) between the two events
+        words = 4 + 5 * (k - 1)
+        res["pass_level"] = dict(stage="post-smoothing on the finest level: 3 Chebyshev operator passes, all kernels (bricks + small slots + tail)",
+                                 words_per_dof=words, ms=float(ms[6, L]), algorithmic_bytes=8.0 * words * N[L],
+                                 achieved_GBps=8.0 * words * N[L] / (ms[6, L] * 1e-3) / 1e9)
+    # reference protocol for context: CG solve to reltol 1e-4 (ref:multigrid_throughput.cc:1238-1254); the reference's
+    # own headline column throughput = n_dofs * n_iterations / time (ref:multigrid_throughput.cc:1282)
     x = h.fine_operator.initialize_dof_vector()
+    m.solve_cg(h.fine_operator, h.mg, x, b, 1e-4)  # warm-up
+    sync()
     t0 = time.perf_counter()
     it, r = m.solve_cg(h.fine_operator, h.mg, x, b, 1e-4)
+    sync()
     res["cg_iterations"], res["cg_time_s"] = it, time.perf_counter() - t0
+    res["cg_throughput"] = h.n_dofs * it / res["cg_time_s"]
     return res
 
 
 def pmc_traffic(n_ref, B):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary of this workload
+    """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 --pmc summary of this workload
     (profiles/*_pmc_traffic_octant<nref>_p4.json, made by tools/pmc_summary.py: FETCH_SIZE x2 + WRITE_SIZE, separate
-    passes), averaged over the kernel's launches like `achieved`; None when no profile of this workload is committed."""
-    import glob
-
+    passes), averaged over the kernel's launches like `achieved`.  It is NOT measured in this run: the source file and the
+    commit that last touched it are returned with it; None when no profile of this workload is committed."""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_traffic_octant{n_ref}_p4.json")))
     if not files:
-        return None
+        return None, None
     rows = [r for r in json.load(open(files[-1]))["kernels"] if f"lattice_apply_kernel<double, 4, {B}, 2>" in r["kernel"]]
     n = sum(r["launches"] for r in rows)
-    return sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows) / n if n else None
+    src = os.path.relpath(files[-1], ROOT)
+    try:
+        src += " @" + subprocess.check_output(["git", "-C", ROOT, "log", "-1", "--format=%h", "--", files[-1]], text=True,
+                                              stderr=subprocess.DEVNULL).strip()
+    except Exception:
+        pass
+    return (sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows) / n if n else None), src
+
+
+def host_cpu_topology():
+    """(usable cores for an OpenMP team, description): physical cores inside this process's affinity mask, capped by the
+    cgroup CPU quota (the GPU boxes of this pool hand a 1-GPU job a share of the host)."""
+    aff = os.sched_getaffinity(0)
+    cores, sockets, cur = set(), set(), {}
+    try:
+        for line in list(open("/proc/cpuinfo")) + [""]:
+            if ":" in line:
+                k, v = line.split(":", 1)
+                cur[k.strip()] = v.strip()
+            elif cur:
+                cpu = int(cur.get("processor", -1))
+                key = (cur.get("physical id", "0"), cur.get("core id", str(cpu)))
+                sockets.add(key[0])
+                if cpu in aff:
+                    cores.add(key)
+                cur = {}
+    except Exception:
+        pass
+    n = len(cores) or len(aff)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(int(q) / int(per)))
+    except Exception:
+        pass
+    use = min(n, quota) if quota else n
+    desc = (f"host: {os.cpu_count()} logical CPUs, {max(len(sockets), 1)} socket(s); this job may use {len(aff)} logical / {n} physical "
+            f"cores" + (f", cgroup quota {quota} CPUs" if quota else "") + f"; OpenMP team {use}")
+    return use, desc
 
 
 def cpu_baseline(m, geometry, n_ref, degree, max_seconds=25.0):
-    """host-CPU baseline: the C++/OpenMP oracle ("port": deal.II cannot be built here) on a bounded sample."""
+    """host-CPU baseline: the C++/OpenMP oracle ("port": deal.II cannot be built here) on a bounded sample: the largest
+    octant level that fits the budget (NRefGlobal 7, 17.6 M DoFs, 1/8 of the GPU workload), every core this job may use."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import cpu_oracle
 
+    cores, desc = host_cpu_topology()
+    cpu_oracle.set_num_threads(cores)
     fine = m.Triangulation(geometry, n_ref)
     trias = m.create_geometric_coarsening_sequence(fine)
     dofs = [m.DoFs(t, degree) for t in trias]
@@ -110,14 +196,21 @@ def cpu_baseline(m, geometry, n_ref, degree, max_seconds=25.0):
     t1 = mg.time_vcycles(b, 1)
     n = int(max(1, min(20, max_seconds / max(t1, 1e-6) / 2)))
     t = mg.time_vcycles(b, n)
-    cores = cpu_oracle.num_threads()
-    cpu_oracle.set_num_threads(1)  # the single-core figure next to it
-    t_one = mg.time_vcycles(b, int(max(1, min(3, 5.0 / max(t * cores, 1e-6)))))
+    out = dict(value=dofs[-1].n_dofs / t, unit="DoF/s", cores=cpu_oracle.num_threads(), kind="port",
+               sample=f"{n} V-cycles of {geometry} NRefGlobal={n_ref} p={degree} ({dofs[-1].n_dofs} DoFs), C++/OpenMP oracle "
+                      f"(host restatement of the reference's CPU path, not deal.II), {t*1e3:.1f} ms/cycle",
+               host=desc, host_cpus=os.cpu_count())
+    # the single-core figure next to it, on the next coarser octant (a 1-core cycle of the sample takes too long)
+    del levels, transfers, mg
+    dofs1 = dofs[:-1]
+    levels, transfers, mg = cpu_oracle.build_from_dofs(dofs1, m.transfer_tables, coarse="direct")
+    cpu_oracle.set_num_threads(1)
+    b1 = dofs1[-1].rhs_constant()
+    t_one = mg.time_vcycles(b1, 2)
     cpu_oracle.set_num_threads(cores)
-    return dict(value=dofs[-1].n_dofs / t, unit="DoF/s", cores=cores, kind="port",
-                sample=f"{n} V-cycles of {geometry} NRefGlobal={n_ref} p={degree} ({dofs[-1].n_dofs} DoFs), C++/OpenMP oracle, "
-                       f"{t*1e3:.1f} ms/cycle",
-                value_1core=dofs[-1].n_dofs / t_one, host_cpus=os.cpu_count())
+    out["value_1core"] = dofs1[-1].n_dofs / t_one
+    out["sample_1core"] = f"2 V-cycles of {geometry} NRefGlobal={n_ref - 1} p={degree} ({dofs1[-1].n_dofs} DoFs), 1 thread"
+    return out
 
 
 def main():
@@ -125,13 +218,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--nref", type=int, default=8, help="NRefGlobal of the primary workload (octant p=4)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="octant_p4")
+    ap.add_argument("--nref", type=int, default=None, help="NRefGlobal of the primary workload (default: 8)")
     ap.add_argument("--nref-p1", type=int, default=9, help="NRefGlobal of the secondary octant p=1 workload")
-    ap.add_argument("--cpu-nref", type=int, default=6, help="NRefGlobal of the CPU-baseline sample")
+    ap.add_argument("--nref-uniform-p1", type=int, default=9, help="NRefGlobal of the uniform-mesh p=1 workload (135 M DoFs)")
+    ap.add_argument("--cpu-nref", type=int, default=7, help="NRefGlobal of the CPU-baseline sample")
     ap.add_argument("--mode", choices=["sharded", "replicas"], default="sharded", help="N > 1: domain decomposition (default) or replicas")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
+    geometry, nref_default, degree, mg_type, coarse, cfg_name = WORKLOADS[args.workload]
+    nref = args.nref if args.nref is not None else nref_default
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -155,27 +252,22 @@ def main():
     import dealii_multigrid_amd as m
 
     ctx = m.Context(local_rank)
-    mode, note = ("single", None) if world == 1 else (args.mode, None)
-    prim = None
-    if mode == "sharded":
-        try:
+    mode = "single" if world == 1 else args.mode
+    comm = None
+    try:
+        if mode == "sharded":
             uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
             if rank == 0:
                 uid.copy_(torch.frombuffer(bytearray(m.Communicator.rccl_unique_id()), dtype=torch.uint8))
             dist.broadcast(uid, 0)
             comm = m.Communicator.rccl(ctx, world, rank, bytes(uid.cpu().numpy().tobytes()))
-            prim = run_workload(m, ctx, "quadrant", args.nref, 4, args.steps, args.warmup, barrier, sync, profile=True, comm=comm)
-            ok = 1.0
-        except Exception as e:  # noqa: BLE001 -- reported in the JSON line, never silent
-            ok, note = 0.0, f"sharded run failed on rank {rank}: {type(e).__name__}: {e}"
-            print(note, file=sys.stderr, flush=True)
-        flag = torch.tensor([ok], device="cuda", dtype=torch.float64)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if flag.item() < 0.5:
-            mode, prim = "replicas", None
-            note = note or "sharded run failed on another rank"
-    if prim is None:
-        prim = run_workload(m, ctx, "quadrant", args.nref, 4, args.steps, args.warmup, barrier, sync, profile=True)
+        prim = run_workload(m, ctx, geometry, nref, degree, mg_type, coarse, args.steps, args.warmup, barrier, sync, profile=True, comm=comm,
+                            details=world == 1)
+    except Exception as e:  # noqa: BLE001
+        # no fallback, no relabelled metric: the other ranks may be blocked inside a collective, so leave hard with a
+        # non-zero status and let the launcher tear the job down
+        print(f"bench.py: rank {rank}/{world} failed ({mode}): {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+        os._exit(3)
     elapsed = prim["elapsed"]
     if dist is not None:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
@@ -185,8 +277,12 @@ def main():
     # sharded: ONE global problem; replicas: N copies of it
     value = (world if mode == "replicas" else 1) * prim["n_dofs"] / (elapsed / args.steps)
 
+    collapsed = ""
+    if prim.get("collapse_level"):
+        collapsed = (f"; levels 0..{prim['collapse_level']} (<= {prim['collapse_level_dofs']} DoFs) applied as ONE tabulated dense matrix "
+                     f"(result-equivalent, see ms_per_step_no_collapse)")
     out = {
-        "metric": "DoF/s per V-cycle, 3D octant p=4",
+        "metric": f"DoF/s per V-cycle, 3D {'octant' if geometry == 'quadrant' else geometry} p={degree}" + (" PMG" if mg_type == "PMG" else ""),
         "value": value,
         "unit": "DoF/s",
         "n_gpus": world,
@@ -199,38 +295,56 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": f"3D octant (GeometryType quadrant) HMG-global p=4 FP64, NRefGlobal={args.nref}, SmootherDegree=3, "
-                        f"coarse solver direct, f=1, zero Dirichlet (BASELINE.json configs[2])",
-            "n_dofs": prim["n_dofs"], "n_cells": prim["n_cells"], "n_levels": prim["n_levels"],
+            "workload": f"3D {'octant (GeometryType quadrant)' if geometry == 'quadrant' else geometry} {mg_type} p={degree} FP64, "
+                        f"NRefGlobal={nref}, SmootherDegree=3, coarse solver {prim['coarse_solver']}, f=1, zero Dirichlet "
+                        f"(BASELINE.json {cfg_name})" + collapsed,
+            "n_dofs": prim["n_dofs"], "n_cells": prim["n_cells"], "n_levels": prim["n_levels"], "level_dofs": prim["level_dofs"],
             "parallelism": "1 GPU" if world == 1 else (
                 f"domain decomposition over {world} GPUs: RCCL send/recv halo exchange + all-reduce onto replicated coarse levels"
                 if mode == "sharded" else f"replicas x{world} (no data-path collective)"),
             "cg_iterations_reltol_1e-4": prim["cg_iterations"],
+            "cg_throughput_dofs_x_iterations_per_s": prim["cg_throughput"],
         },
     }
-    if note:
-        out["config"]["note"] = note
+    if "ms_no_collapse" in prim:
+        out["ms_per_step_no_collapse"] = prim["ms_no_collapse"]
     if "halo" in prim:
         out["config"]["halo_rank0"] = prim["halo"]
     # whole-V-cycle roofline figure (against the aggregate HBM bandwidth of the GPUs used) and the dominant kernel's
     vcycle_gbs = (world if mode == "replicas" else 1) * prim["bytes_per_vcycle"] / (elapsed / args.steps) / 1e9 / world
     out["vcycle_algorithmic_GBps_per_gpu"] = vcycle_gbs
     out["vcycle_frac_of_hbm_peak"] = vcycle_gbs / HBM_PEAK_GBS
-    out["vcycle_bytes_model"] = "SURVEY 8(d): 8 B x [(10k+3) sum_{l>=1} N_l + 2 sum_{l<L} N_l], k=3"
+    out["vcycle_bytes_model"] = ("SURVEY 8(d): 8 B x [(10k+3) sum_{l>=1} N_l + 2 sum_{l<L} N_l], k=3 (the reference algorithm's compulsory "
+                                 "traffic; this implementation never stores x_1 of the zero-start smoother and moves 5 words per DoF and "
+                                 "level fewer, so this fraction is the model's bytes over time, not achieved bandwidth)")
     if prim["prof"] and prim["prof"][1] > 0:
         ms, n, by = prim["prof"]
         achieved = by / (ms * 1e-3) / 1e9
-        B = max(prim["groups"], key=lambda g: g[1] * (4 * g[0] + 1) ** 3)[0]
+        B = max(prim["groups"], key=lambda g: g[1] * (degree * g[0] + 1) ** 3)[0]
+        traffic, traffic_src = pmc_traffic(nref, B) if args.workload == "octant_p4" else (None, None)
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                           "traffic": pmc_traffic(args.nref, B),
-                           "kernel": f"lattice_apply_kernel<double,4,{B},MODE_CHEB> (the Chebyshev passes that read x and x_old from memory: "
-                                     f"5 words/DoF with x_old, 4 without; all launches of this symbol in the timed region)",
+                           "traffic": traffic, "traffic_source": traffic_src,
+                           "kernel": f"lattice_apply_kernel<double,{degree},{B},MODE_CHEB> (the Chebyshev passes that read x and x_old from memory; all "
+                                     f"launches of this symbol in the timed region).  Algorithmic bytes per brick: 5 (4 without x_old) words x "
+                                     f"{(degree * B - 1) ** 3} slot-interior DoFs + 2 words (gathered x, partial sum) x {(degree * B) ** 3 - (degree * B - 1) ** 3} shell DoFs "
+                                     f"whose epilogue tail_kernel finishes",
                            "launches": n, "avg_launch_us": ms / n * 1e3, "algorithmic_bytes_per_launch": by / n}
-    if not args.no_secondary and (rank == 0 or mode == "sharded"):
+        if "pass_level" in prim:
+            pl = dict(prim["pass_level"])
+            pl["frac"] = pl["achieved_GBps"] / HBM_PEAK_GBS
+            out["roofline"]["pass_level"] = pl
+    for k in ("stage_ms_finest", "stage_ms_total", "stage_ms_per_level"):
+        if k in prim:
+            out[k] = prim[k]
+    if not args.no_secondary and args.workload == "octant_p4" and (rank == 0 or mode == "sharded"):
         # octant p=1: on one GPU (rank 0), or sharded like the primary workload when that ran sharded
         sharded2 = mode == "sharded"
-        sec = run_workload(m, ctx, "quadrant", args.nref_p1, 1, args.steps, args.warmup, barrier if sharded2 else (lambda: None), sync,
-                           profile=False, comm=comm if sharded2 else None)
+        try:
+            sec = run_workload(m, ctx, "quadrant", args.nref_p1, 1, "HMG-global", "amg", args.steps, args.warmup,
+                               barrier if sharded2 else (lambda: None), sync, profile=False, comm=comm if sharded2 else None, details=world == 1)
+        except Exception as e:  # noqa: BLE001
+            print(f"bench.py: rank {rank}/{world} failed in the p=1 workload: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+            os._exit(3)
         t = sec["elapsed"]
         if sharded2:
             tt = torch.tensor([t], device="cuda", dtype=torch.float64)
@@ -241,6 +355,18 @@ def main():
                        "n_gpus": world if sharded2 else 1, "ms_per_step": t * 1e3, "n_dofs": sec["n_dofs"], "NRefGlobal": args.nref_p1,
                        "vcycle_frac_of_hbm_peak": sec["bytes_per_vcycle"] / t / 1e9 / HBM_PEAK_GBS / (world if sharded2 else 1),
                        "cg_iterations_reltol_1e-4": sec["cg_iterations"]}
+        for k in ("ms_no_collapse", "collapse_level", "collapse_level_dofs", "stage_ms_per_level"):
+            if k in sec:
+                out["also"][k] = sec[k]
+        if world == 1:
+            # BASELINE.json configs[1]: p = 1 on a uniformly refined mesh that fills the GPU (135 M DoFs)
+            uni = run_workload(m, ctx, "hypercube", args.nref_uniform_p1, 1, "HMG-global", "amg", max(args.steps // 2, 3), 2, lambda: None, sync,
+                               profile=False)
+            tu = uni["elapsed"] / max(args.steps // 2, 3)
+            out["also_uniform_p1"] = {"metric": "DoF/s per V-cycle, 3D uniform cube p=1 (BASELINE.json configs[1])", "value": uni["n_dofs"] / tu,
+                                      "unit": "DoF/s", "n_gpus": 1, "ms_per_step": tu * 1e3, "n_dofs": uni["n_dofs"],
+                                      "NRefGlobal": args.nref_uniform_p1, "vcycle_frac_of_hbm_peak": uni["bytes_per_vcycle"] / tu / 1e9 / HBM_PEAK_GBS,
+                                      "cg_iterations_reltol_1e-4": uni["cg_iterations"]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(m, "quadrant", args.cpu_nref, 4)
     barrier()

@@ -483,6 +483,12 @@ class PreconditionMG:
             _chk(_lib.mgamd_mg_create_nested(ctx._h, n, L, T, S, coarse_solver.encode(), nested._h, n_cycles, C.byref(self._h)))
         self._cb = None
 
+    def set_collapse(self, enable: bool) -> int:
+        """switch the tabulated coarse levels off/on; returns the collapse level (0: none)"""
+        l = C.c_uint()
+        _chk(_lib.mgamd_mg_set_collapse(self._h, 1 if enable else 0, C.byref(l)))
+        return l.value
+
     def coarse_solver_used(self) -> str:
         buf = C.create_string_buffer(32)
         _chk(_lib.mgamd_mg_coarse_solver_used(self._h, buf))
@@ -589,26 +595,63 @@ class Hierarchy:
 
 
 class DistributedHierarchy:
-    """One rank's share of the hierarchy: levels below the partition's root level are replicated, the others hold this
-    rank's cells and exchange the partial sums of shared DoFs through `comm` (RCCL over xGMI in production)."""
+    """One rank's share of the hierarchy (HMG-global, PMG or HPMG): levels on meshes below the partition's root level are
+    replicated, the others hold this rank's cells and exchange the partial sums of shared DoFs through `comm` (RCCL over
+    xGMI in production).  The p-levels of PMG/HPMG live on the finest mesh: they inherit its partition, p-transfers are
+    rank-local, and the p = 1 coarse problem of PMG is solved by the distributed CG (+ Chebyshev) or, for the AMG choices,
+    by V-cycles of the (equally sharded) h-multigrid below it."""
 
     def __init__(self, ctx: Context, comm: Communicator, geometry="quadrant", n_ref_global=3, degree=1, smoother_degree=3,
                  smoothing_range=20.0, eig_cg_n_iterations=20, coarse_solver="amg", number_type=F64, hanging_weight=2.0, max_brick=-1,
-                 min_root_dofs=4_000_000):
+                 min_root_dofs=4_000_000, mg_type="HMG-global", coarse_n_cycles=1):
         self.ctx, self.comm = ctx, comm
         fine = Triangulation(geometry, n_ref_global)
-        self.trias = create_geometric_coarsening_sequence(fine)
+        self.mesh_sequence = create_geometric_coarsening_sequence(fine)
+        nm = len(self.mesh_sequence)
+        # (mesh index, degree) of every multigrid level, coarse -> fine (ref:multigrid_throughput.cc:1506-1571)
+        if mg_type == "HMG-global":
+            plan = [(l, degree) for l in range(nm)]
+        elif mg_type == "PMG":
+            plan = [(nm - 1, p) for p in create_polynomial_coarsening_sequence(degree)]
+        elif mg_type == "HPMG":
+            pseq = create_polynomial_coarsening_sequence(degree)
+            plan = [(l, pseq[0]) for l in range(nm)] + [(nm - 1, p) for p in pseq[1:]]
+        else:
+            raise MgamdError(f"Type '{mg_type}' not implemented")
         # levels below ~4 M DoFs stay replicated: their single-GPU time (latency-bound: 0.34 ms for 2.3 M DoFs at p=4,
         # 0.33 ms for 2.2 M at p=1) is below what a distributed level pays for its 8 halo exchanges per cycle on top of its
         # own (also latency-bound) kernels
-        self.partition = Partition(self.trias, comm.n_ranks, hanging_weight, min_root_dofs // degree ** 3)
-        nl = len(self.trias)
-        self.dofs = [DoFs(self.trias[l], degree, max_brick, self.partition, l, comm.rank) for l in range(nl)]
-        self.operators = [Operator(ctx, self.dofs[l], number_type, comm if l >= self.partition.root_level and comm.n_ranks > 1 else None)
-                          for l in range(nl)]
-        self.transfers = [None] + [MGTwoLevelTransfer(self.operators[l], self.operators[l - 1]) for l in range(1, nl)]
-        self.smoothers = [PreconditionChebyshev(op, smoother_degree, smoothing_range, eig_cg_n_iterations) for op in self.operators]
-        self.mg = PreconditionMG(ctx, self.operators, self.transfers, self.smoothers, coarse_solver)
+        p_low = min(p for _, p in plan)
+        self.partition = Partition(self.mesh_sequence, comm.n_ranks, hanging_weight, min_root_dofs // p_low ** 3)
+        sharded = comm.n_ranks > 1
+
+        def build(levels, shared_level0=None):
+            """levels: list of (mesh index, degree); shared_level0: (dofs, operator, smoother) reused as the LAST level"""
+            dofs = [DoFs(self.mesh_sequence[mi], p, max_brick, self.partition, mi, comm.rank) for mi, p in levels]
+            dist = [sharded and mi >= self.partition.root_level for mi, _ in levels]
+            if shared_level0 is not None:
+                dofs[-1] = shared_level0[0]
+            ops = [Operator(ctx, d, number_type, comm if dist[l] else None) for l, d in enumerate(dofs)]
+            if shared_level0 is not None:
+                ops[-1] = shared_level0[1]
+            tr = [None] + [MGTwoLevelTransfer(ops[l], ops[l - 1]) for l in range(1, len(ops))]
+            sm = [PreconditionChebyshev(op, smoother_degree, smoothing_range, eig_cg_n_iterations) for op in ops]
+            if shared_level0 is not None:
+                sm[-1] = shared_level0[2]
+            return dofs, dist, ops, tr, sm
+
+        self.trias = [self.mesh_sequence[mi] for mi, _ in plan]
+        self.degrees = [p for _, p in plan]
+        self.dofs, self.distributed, self.operators, self.transfers, self.smoothers = build(plan)
+        self.coarse = None
+        n0 = (int(round(comm.allreduce_sum(ctx, float(self.operators[0].n_owned())))) if self.distributed[0] else self.dofs[0].n_dofs)
+        if coarse_solver in AMG_COARSE_SOLVERS and n0 > 4096:
+            # geometric stand-in for the AMG coarse solvers: the h-multigrid on level 0's space (mgamd.h, "gmg_vcycle")
+            mi0, p0 = plan[0]
+            cd, cdist, cops, ctr, csm = build([(l, p0) for l in range(mi0 + 1)], (self.dofs[0], self.operators[0], self.smoothers[0]))
+            self.coarse = PreconditionMG(ctx, cops, ctr, csm, "amg")
+            self.coarse.parts = (cd, cdist)
+        self.mg = PreconditionMG(ctx, self.operators, self.transfers, self.smoothers, coarse_solver, self.coarse, coarse_n_cycles)
         self.fine_operator = self.operators[-1]
         self.n_local = self.dofs[-1].n_dofs
         self.n_dofs = int(round(comm.allreduce_sum(ctx, float(self.fine_operator.n_owned()))))

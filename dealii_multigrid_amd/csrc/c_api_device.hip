@@ -559,6 +559,17 @@ mgamd_mg_create_nested(mgamd_ctx *ctx, unsigned n_levels, mgamd_level_op *const 
 }
 
 int
+mgamd_mg_set_collapse(mgamd_mg *mg, int enable, unsigned *collapse_level)
+{
+  MGAMD_TRY
+  REQUIRE(mg);
+  const unsigned l = mg->mg->set_collapse(enable != 0);
+  if (collapse_level)
+    *collapse_level = l;
+  MGAMD_CATCH
+}
+
+int
 mgamd_mg_coarse_solver_used(const mgamd_mg *mg, char name[32])
 {
   MGAMD_TRY

@@ -704,8 +704,11 @@ namespace mgamd
       auto prof_end = [&](const GroupDev<T> &g, size_t n_slots) {
         HIP_CHECK(hipEventRecord(ctx->prof_events[ctx->prof_used].second, main));
         ++ctx->prof_used;
-        const double n1 = (double)(g.N - 1);
-        ctx->prof_bytes += words * sizeof(T) * (double)n_slots * n1 * n1 * n1;
+        // algorithmic bytes of THIS kernel: `words` per slot-interior DoF (the fused epilogue is complete for them); for
+        // the (N-1)^3 - (N-2)^3 shell DoFs a brick is responsible for, one gathered word and one partial sum (the other
+        // words of their epilogue are tail_kernel's)
+        const double n1 = (double)(g.N - 1), n2 = (double)(g.N - 2);
+        ctx->prof_bytes += sizeof(T) * (double)n_slots * (words * n2 * n2 * n2 + 2.0 * (n1 * n1 * n1 - n2 * n2 * n2));
       };
       // every group but the pipelined one
       for (size_t gi = 0; gi < groups.size(); ++gi)
@@ -1518,6 +1521,13 @@ namespace mgamd
     // reference's per-level timers need the real stages).
     unsigned     collapse_level = 0;
     DBuf<double> collapse_M;
+    bool         collapse_enabled = true;
+    unsigned
+    set_collapse(bool on) override
+    {
+      collapse_enabled = on;
+      return collapse_level;
+    }
     DBuf<T>                          cg_r, cg_z, cg_p, cg_Ap;
     hipGraphExec_t                   graph_exec = nullptr;
     const void                      *graph_z = nullptr, *graph_r = nullptr;
@@ -1790,11 +1800,12 @@ namespace mgamd
     coarse_cg(T *x, const T *b, bool with_cheb)
     {
       // SolverCG + ReductionControl(maxiter 10000, abstol 1e-20, reltol 1e-4): ref:multigrid_throughput.cc:888-895
+      // (inner products over the GLOBAL vector: on a sharded level every DoF counts once, one scalar all-reduce each)
       const size_t n = ops[0]->n_dofs();
       const int    g = grid_for(n);
       HIP_CHECK(hipMemsetAsync(x, 0, n * sizeof(T), ctx->stream));
       HIP_CHECK(hipMemcpyAsync(cg_r.p, b, n * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
-      const double res0 = std::sqrt(dot_raw(ctx, cg_r.p, cg_r.p, n));
+      const double res0 = std::sqrt(ops[0]->dot_raw_global(cg_r.p, cg_r.p));
       if (res0 <= 1e-20)
         return;
       auto precond = [&]() {
@@ -1805,18 +1816,18 @@ namespace mgamd
       };
       precond();
       HIP_CHECK(hipMemcpyAsync(cg_p.p, cg_z.p, n * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
-      double rz = dot_raw(ctx, cg_r.p, cg_z.p, n);
+      double rz = ops[0]->dot_raw_global(cg_r.p, cg_z.p);
       for (unsigned it = 1; it <= 10000; ++it)
         {
           ops[0]->vmult_raw(cg_Ap.p, cg_p.p);
-          const double alpha = rz / dot_raw(ctx, cg_p.p, cg_Ap.p, n);
+          const double alpha = rz / ops[0]->dot_raw_global(cg_p.p, cg_Ap.p);
           hipLaunchKernelGGL(vec_sadd_kernel<T>, g, 256, 0, ctx->stream, x, T(1), T(alpha), cg_p.p, n);
           hipLaunchKernelGGL(vec_sadd_kernel<T>, g, 256, 0, ctx->stream, cg_r.p, T(1), T(-alpha), cg_Ap.p, n);
-          const double res = std::sqrt(dot_raw(ctx, cg_r.p, cg_r.p, n));
+          const double res = std::sqrt(ops[0]->dot_raw_global(cg_r.p, cg_r.p));
           if (res < 1e-4 * res0 || res <= 1e-20)
             break;
           precond();
-          const double rz_new = dot_raw(ctx, cg_r.p, cg_z.p, n);
+          const double rz_new = ops[0]->dot_raw_global(cg_r.p, cg_z.p);
           const double beta   = rz_new / rz;
           rz                  = rz_new;
           hipLaunchKernelGGL(vec_sadd_kernel<T>, g, 256, 0, ctx->stream, cg_p.p, T(beta), T(1), cg_z.p, n);
@@ -1851,7 +1862,7 @@ namespace mgamd
           stage(3, false, 0);
           return;
         }
-      if (l == collapse_level && !cb)
+      if (l == collapse_level && !cb && collapse_enabled)
         {
           // the tabulated cycle below this level: timed as the coarse solve of level l
           const size_t n = ops[l]->n_dofs();

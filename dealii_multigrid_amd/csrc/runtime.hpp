@@ -232,6 +232,9 @@ namespace mgamd
     time_vcycles(mgamd_vec &z, const mgamd_vec &r, unsigned n, bool use_graph) = 0;
     virtual unsigned
     n_levels() const = 0;
+    // switch the tabulated (collapsed) coarse levels on/off at run time; returns the collapse level (0: none)
+    virtual unsigned
+    set_collapse(bool on) = 0;
     // the coarse solver actually in use ("direct", "cg", "cg_with_chebyshev", "gmg_vcycle")
     std::string coarse_used;
     int         number_type = MGAMD_F64;

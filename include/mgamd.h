@@ -241,6 +241,11 @@ int mgamd_mg_create_nested(mgamd_ctx *ctx, unsigned n_levels, mgamd_level_op *co
                            mgamd_cheb *const *smoothers, const char *coarse_solver, mgamd_mg *coarse_mg, unsigned n_cycles,
                            mgamd_mg **out);
 int mgamd_mg_coarse_solver_used(const mgamd_mg *mg, char name[32]);
+/* Levels up to 2048 DoFs (MGAMD_COLLAPSE_MAX_DOFS) with a direct coarse solver are applied as ONE tabulated dense matrix
+ * (the zero-start V-cycle below a level is a linear map of its defect; result-equivalent).  This switches the
+ * tabulated path off/on at run time (bench.py reports the cycle time both ways); *collapse_level = the level it replaces
+ * (0: none). */
+int mgamd_mg_set_collapse(mgamd_mg *mg, int enable, unsigned *collapse_level);
 int mgamd_mg_destroy(mgamd_mg *mg);
 /* PreconditionMG::vmult: z = V-cycle(r)  (ref:multigrid_throughput.cc:1132-1133) -- the metric's unit of work.
  * z and r are vectors of the finest level's outer number type (double). */

@@ -535,11 +535,15 @@ def lanczos_from_cg(alphas, betas):
 
 
 class Chebyshev:
-    def __init__(self, A, inv_diag, degree=3, smoothing_range=20.0, eig_cg_n_iterations=20, number=np.float64):
+    def __init__(self, A, inv_diag, degree=3, smoothing_range=20.0, eig_cg_n_iterations=20, number=np.float64, start=None):
+        """start: start vector of the eigenvalue estimate; default deal.II's (i mod 11) - mean"""
         self.A, self.dinv, self.k = A, inv_diag, degree
         n = A.shape[0]
-        v = (np.arange(n) % 11).astype(number)
-        v = v - v.mean()
+        if start is None:
+            v = (np.arange(n) % 11).astype(number)
+            v = v - v.mean()
+        else:
+            v = np.array(start, dtype=number)
         # PCG with D^-1, x0 = 0, at most eig_cg_n_iterations iterations, tol 1e-10 (IterationNumberControl)
         x = np.zeros(n)
         r = v.copy()
@@ -630,14 +634,41 @@ def pcg(A, b, precond, reltol=1e-4, abstol=1e-20, maxiter=10000, x0=None):
     return x, it, hist
 
 
+def key_hash_start_vector(level):
+    """Numbering-independent start vector of the eigenvalue estimate, as the product's sharded runs define it (there is no
+    global DoF index across ranks): a 64-bit mix of the packed geometric DoF key, mod 11, on unconstrained DoFs, minus
+    its mean over them; zero on constrained DoFs."""
+    M = (1 << 64) - 1
+
+    def mix(x):
+        x ^= x >> 33
+        x = (x * 0xff51afd7ed558ccd) & M
+        x ^= x >> 33
+        x = (x * 0xc4ceb9fe1a85ec53) & M
+        x ^= x >> 33
+        return x
+
+    v = np.zeros(level.n)
+    for i, (px, py, pz, dm, lev) in enumerate(level.keys):
+        if not level.constrained[i]:
+            v[i] = mix(((px << 43) | (py << 25) | (pz << 7) | (dm << 4) | (lev if dm else 0)) & M) % 11
+    free = ~level.constrained
+    if free.any():
+        v[free] -= v[free].mean()
+    return v
+
+
 # ----------------------------------------------------------------------------
 # Multigrid V-cycle (deal.II Multigrid::level_v_step / PreconditionMG, SURVEY 3.3)
 # ----------------------------------------------------------------------------
 class Multigrid:
     def __init__(self, levels, transfers, smoother_degree=3, smoothing_range=20.0, eig_cg_n_iterations=20,
-                 coarse="direct", coarse_reltol=1e-4):
+                 coarse="direct", coarse_reltol=1e-4, start_vectors=None):
+        """start_vectors: per level the start vector of the smoother's eigenvalue estimate (default: deal.II's index-based
+        one); key_hash_start_vector(level) gives the numbering-independent vector the product's sharded runs use"""
         self.levels, self.P = levels, transfers  # P[l]: level l-1 -> l  (P[0] unused)
-        self.sm = [Chebyshev(L.A, L.inv_diag, smoother_degree, smoothing_range, eig_cg_n_iterations) for L in levels]
+        sv = start_vectors or [None] * len(levels)
+        self.sm = [Chebyshev(L.A, L.inv_diag, smoother_degree, smoothing_range, eig_cg_n_iterations, start=sv[l]) for l, L in enumerate(levels)]
         self.coarse, self.coarse_reltol = coarse, coarse_reltol
         if coarse == "direct":
             self.A0 = spla.splu(sp.csc_matrix(levels[0].A))

@@ -46,6 +46,112 @@ def key_based_chebyshev_start_vector():
     del os.environ["MGAMD_CHEB_KEY_INIT"]
 
 
+def key_vector(keys, seed):
+    """deterministic pseudo-random value per geometric DoF key: the same GLOBAL vector on every rank and in the oracle"""
+    k = np.asarray(keys, dtype=np.int64)
+    h = (k[:, 0] * 73856093) ^ (k[:, 1] * 19349663) ^ (k[:, 2] * 83492791) ^ (k[:, 3] * 2654435761) ^ (k[:, 4] * 97) ^ seed
+    return np.sin(h.astype(np.float64) * 1e-3) + 0.25 * np.cos(h.astype(np.float64) * 7e-5)
+
+
+# (geometry, NRefGlobal, degree, Type, coarse solver, ranks): vs the INDEPENDENT numpy oracle through the DoF keys
+ORACLE_CASES = [("quadrant", 5, 1, "HMG-global", "amg", 2), ("quadrant", 4, 4, "HMG-global", "amg", 2), ("quadrant", 5, 2, "HMG-global", "amg", 3),
+                ("annulus", 6, 1, "HMG-global", "amg", 4), ("hypercube", 4, 2, "HMG-global", "amg", 2),
+                ("annulus", 5, 4, "PMG", "cg_with_chebyshev", 2),  # BASELINE.json configs[4] at test size
+                ("quadrant", 4, 4, "PMG", "cg", 3), ("annulus", 5, 2, "HPMG", "amg", 3),
+                ("annulus", 6, 2, "PMG", "amg", 2)]  # AMG on a 9,763-DoF coarse level: sharded geometric stand-in = HPMG
+
+
+@pytest.mark.parametrize("geo,L,p,mg_type,coarse,n_ranks", ORACLE_CASES)
+def test_sharded_hierarchy_matches_numpy_oracle(mgamd, oracle, geo, L, p, mg_type, coarse, n_ranks):
+    """operator, V-cycle and preconditioned solve of the SHARDED hierarchy (partition, local numbering, halo exchange,
+    rank-local transfers, all-reduce onto replicated levels, distributed coarse CG, global dots) against the independent
+    numpy oracle, matched through the geometric DoF keys; copies of shared DoFs identical on all sharers."""
+    stand_in = mg_type == "PMG" and coarse == "amg"
+    levels, P = oracle.build_hierarchy(geo, L, p, "HPMG" if stand_in else mg_type)
+    omg = oracle.Multigrid(levels, P, 3, coarse="direct" if coarse == "amg" else coarse,
+                           start_vectors=[oracle.key_hash_start_vector(lv) for lv in levels])
+    Lf = levels[-1]
+    kf = {tuple(int(v) for v in k): i for i, k in enumerate(Lf.keys)}
+    u = key_vector(Lf.keys, 1)
+    r = key_vector(Lf.keys, 2)
+    r[Lf.constrained] = 0.0
+    Au, zref = Lf.A @ u, omg.vcycle(r)
+    xref, itref, hist = oracle.pcg(Lf.A, Lf.rhs_constant, omg.vcycle, 1e-4)
+    group = mgamd.SimGroup(n_ranks)
+
+    def rank_main(rk):
+        ctx = mgamd.Context(0)
+        h = mgamd.DistributedHierarchy(ctx, group.comm(rk), geo, L, p, coarse_solver=coarse, max_brick=0, min_root_dofs=0, mg_type=mg_type)
+        keys = keyset(h.dofs[-1].keys())
+        idx = np.array([kf[k] for k in keys])
+        op = h.fine_operator
+        vu, vA = op.initialize_dof_vector().from_host(u[idx]), op.initialize_dof_vector()
+        op.vmult(vA, vu)
+        vr, vz = op.initialize_dof_vector().from_host(r[idx]), op.initialize_dof_vector()
+        h.mg.vmult(vz, vr)
+        b, x = op.initialize_dof_vector(), op.initialize_dof_vector()
+        op.rhs(b)
+        it, res = mgamd.solve_cg(op, h.mg, x, b, 1e-4)
+        return dict(idx=idx, Au=vA.to_host(), z=vz.to_host(), x=x.to_host(), b=b.to_host(), it=it, res=res, n_dofs=h.n_dofs,
+                    dist=list(h.distributed), used=h.mg.coarse_solver_used(), peers=h.dofs[-1].info.n_peers)
+
+    out = run_ranks(n_ranks, rank_main)
+    tol_v, tol_x = (1e-11, 1e-10) if coarse == "amg" else (1e-4, 1e-5)  # an inner CG stops on a tolerance
+    for o in out:
+        assert o["n_dofs"] == Lf.n and o["peers"] >= 1 and o["dist"][-1]
+        assert o["used"] == ("gmg_vcycle" if stand_in else ("direct" if coarse == "amg" else coarse))
+        assert rel_err(o["Au"], Au[o["idx"]]) < 1e-13
+        assert np.abs(o["b"] - Lf.rhs_constant[o["idx"]]).max() < 1e-14
+        assert rel_err(o["z"], zref[o["idx"]]) < tol_v
+        assert o["it"] == itref
+        assert rel_err(o["x"], xref[o["idx"]]) < tol_x
+    if mg_type == "PMG":
+        assert all(out[0]["dist"])  # the p-levels live on the finest mesh: all distributed
+    if mg_type == "HPMG":
+        assert out[0]["dist"][-2] and not out[0]["dist"][0]
+    # copies of shared DoFs agree across ranks (bitwise: ascending-rank combination order)
+    seen = {}
+    for o in out:
+        for i, v in zip(o["idx"], o["x"]):
+            if i in seen:
+                assert seen[i] == v
+            seen[i] = v
+    assert len(seen) == Lf.n
+
+
+def test_eight_ranks_balanced_and_consistent(mgamd):
+    """octant L=6 p=4 (2.3 M DoFs) on 8 simulated ranks: weights (hanging-node cells x 2, CellWeightPolicy-2.0) balanced to
+    10 %, result equal to the single-rank solve."""
+    geo, L, p, n_ranks = "quadrant", 6, 4, 8
+    ctx0 = mgamd.Context(0)
+    h0 = mgamd.Hierarchy(ctx0, geo, L, p, "HMG-global", coarse_solver="amg", max_brick=0)
+    b0, x0 = h0.fine_operator.initialize_dof_vector(), h0.fine_operator.initialize_dof_vector()
+    h0.fine_operator.rhs(b0)
+    it0, res0 = mgamd.solve_cg(h0.fine_operator, h0.mg, x0, b0, 1e-4)
+    ref = dict(zip(keyset(h0.dofs[-1].keys()), x0.to_host()))
+    trias = h0.trias
+    part = mgamd.Partition(trias, n_ranks, 2.0, 0)
+    owner = part.owner(len(trias) - 1)
+    _, _, _, _, mask = trias[-1].cells()
+    w = np.where((mask >> 3) != 0, 2.0, 1.0)
+    load = np.array([w[owner == rk].sum() for rk in range(n_ranks)])
+    assert load.max() / load.mean() < 1.10
+    group = mgamd.SimGroup(n_ranks)
+
+    def rank_main(rk):
+        ctx = mgamd.Context(0)
+        h = mgamd.DistributedHierarchy(ctx, group.comm(rk), geo, L, p, coarse_solver="amg", max_brick=0, min_root_dofs=0)
+        b, x = h.fine_operator.initialize_dof_vector(), h.fine_operator.initialize_dof_vector()
+        h.fine_operator.rhs(b)
+        it, res = mgamd.solve_cg(h.fine_operator, h.mg, x, b, 1e-4)
+        return dict(it=it, keys=keyset(h.dofs[-1].keys()), x=x.to_host(), n_dofs=h.n_dofs, peers=h.dofs[-1].info.n_peers)
+
+    out = run_ranks(n_ranks, rank_main)
+    for o in out:
+        assert o["n_dofs"] == h0.n_dofs and o["it"] == it0 and 1 <= o["peers"] <= 7
+        assert rel_err(o["x"], np.array([ref[k] for k in o["keys"]])) < 1e-10
+
+
 @pytest.mark.parametrize("geo,L,p,n_ranks", [("quadrant", 5, 1, 2), ("quadrant", 4, 4, 2), ("quadrant", 5, 2, 3), ("annulus", 6, 1, 4),
                                              ("hypercube", 4, 2, 2), ("quadrant", 5, 4, 4)])
 def test_sharded_solve_matches_single_rank(mgamd, geo, L, p, n_ranks):
