@@ -223,12 +223,14 @@ def main():
     ap.add_argument("--nref-p1", type=int, default=9, help="NRefGlobal of the secondary octant p=1 workload")
     ap.add_argument("--nref-uniform-p1", type=int, default=9, help="NRefGlobal of the uniform-mesh p=1 workload (135 M DoFs)")
     ap.add_argument("--cpu-nref", type=int, default=7, help="NRefGlobal of the CPU-baseline sample")
+    ap.add_argument("--coarse", default=None, help="CoarseGridSolverType override (pmg_annulus: cg_with_chebyshev | cg | amg = geometric stand-in)")
     ap.add_argument("--mode", choices=["sharded", "replicas"], default="sharded", help="N > 1: domain decomposition (default) or replicas")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
     geometry, nref_default, degree, mg_type, coarse, cfg_name = WORKLOADS[args.workload]
     nref = args.nref if args.nref is not None else nref_default
+    coarse = args.coarse or coarse
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -2346,6 +2346,65 @@ namespace mgamd
       *result = wsum[0] + wsum[1] + wsum[2] + wsum[3];
   }
 
+  // ------------------------------------------------------------------------------------------
+  // Device-resident PCG (SolverCG, ref:multigrid_throughput.cc:1143-1144,1625-1635): every scalar of the iteration lives
+  // in a small device array S; the vector updates read alpha/beta from it and are fused with the reductions they feed.
+  // The host reads ONE number per iteration (the residual norm, for ReductionControl).
+  //   S[0], S[1]: r.z of the current / next iteration (ping-pong)   S[2]: p.Ap   S[3]: r.r
+  // ------------------------------------------------------------------------------------------
+  template <typename T>
+  __global__ void
+  __launch_bounds__(256) cg_dot_kernel(const T *__restrict__ x, const T *__restrict__ y, size_t n, double *__restrict__ partial)
+  {
+    __shared__ double wsum[4];
+    double            s      = 0.0;
+    const size_t      stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+      s += (double)x[i] * (double)y[i];
+    s = wave_reduce_sum(s);
+    if ((threadIdx.x & 63) == 0)
+      wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      partial[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  }
+  // x += alpha p, r -= alpha Ap with alpha = S[rz] / S[2], fused with the partial sums of r.r over the first n_dot entries
+  // (n_dot <= n: the owned prefix on a sharded level)
+  template <typename T>
+  __global__ void
+  __launch_bounds__(256) cg_update_xr_kernel(T *__restrict__ x, T *__restrict__ r, const T *__restrict__ p, const T *__restrict__ Ap, size_t n,
+                                             size_t n_dot, const double *__restrict__ S, int rz, double *__restrict__ partial)
+  {
+    __shared__ double wsum[4];
+    const T           alpha  = (T)(S[rz] / S[2]);
+    double            s      = 0.0;
+    const size_t      stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+      {
+        x[i] += alpha * p[i];
+        const T rn = r[i] - alpha * Ap[i];
+        r[i]       = rn;
+        if (i < n_dot)
+          s += (double)rn * (double)rn;
+      }
+    s = wave_reduce_sum(s);
+    if ((threadIdx.x & 63) == 0)
+      wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      partial[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  }
+  // p = z + beta p with beta = S[rz_new] / S[rz_old]
+  template <typename T>
+  __global__ void
+  __launch_bounds__(256) cg_update_p_kernel(T *__restrict__ p, const T *__restrict__ z, size_t n, const double *__restrict__ S, int rz_new, int rz_old)
+  {
+    const T      beta   = (T)(S[rz_new] / S[rz_old]);
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+      p[i] = z[i] + beta * p[i];
+  }
+
   // y = Minv x for the coarse-grid direct solve (Minv: n x n row-major, double)
   template <typename T>
   __global__ void

@@ -33,6 +33,7 @@ namespace mgamd
       HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_CHECK(hipMalloc((void **)&d_partial, 1024 * sizeof(double)));
     HIP_CHECK(hipMalloc((void **)&d_result, 8 * sizeof(double)));
+    HIP_CHECK(hipMalloc((void **)&d_cg, 8 * sizeof(double)));
     HIP_CHECK(hipHostMalloc((void **)&h_result, 8 * sizeof(double)));
   }
 
@@ -50,6 +51,7 @@ namespace mgamd
       }
     (void)hipFree(d_partial);
     (void)hipFree(d_result);
+    (void)hipFree(d_cg);
     (void)hipHostFree(h_result);
     (void)hipStreamDestroy(stream);
   }
@@ -163,6 +165,70 @@ namespace mgamd
     HIP_CHECK(hipMemcpyAsync(ctx->h_result, ctx->d_result, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     ctx->sync();
     return ctx->h_result[0];
+  }
+
+  // S[slot] = x . y over the first n entries, summed over the ranks of `comm` (stream-ordered, no host synchronisation)
+  template <typename T>
+  static void
+  dot_to_device(Ctx *ctx, Comm *comm, double *S, const T *x, const T *y, size_t n, int slot)
+  {
+    int g = std::min(grid_for(std::max<size_t>(n, 1)), 1024);
+    hipLaunchKernelGGL(cg_dot_kernel<T>, g, 256, 0, ctx->stream, x, y, n, ctx->d_partial);
+    hipLaunchKernelGGL(vec_dot_final_kernel, 1, 256, 0, ctx->stream, ctx->d_partial, g, S + slot);
+    if (comm)
+      comm->allreduce_sum(S + slot, 1, MGAMD_F64, ctx->stream);
+  }
+  static double
+  read_scalar(Ctx *ctx, const double *S, int slot)
+  {
+    HIP_CHECK(hipMemcpyAsync(ctx->h_result, S + slot, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ctx->sync();
+    return ctx->h_result[0];
+  }
+
+  // Device-resident preconditioned CG from x = 0 (SolverCG + ReductionControl: ref:multigrid_throughput.cc:1143-1144,
+  // 888-895).  vmult(Ap, p) and precond(z, r) enqueue work on the stream; r holds b on entry.  n_dot: entries counted by
+  // the inner products (the owned prefix on a sharded level, all otherwise).  One host read-back per iteration (the
+  // residual norm); alpha, beta and the three inner products never leave the device: they live in S (8 doubles, one array per
+  // solver instance -- the coarse CG of a V-cycle runs INSIDE the outer CG's preconditioner).
+  template <typename T, typename VMULT, typename PRECOND>
+  static void
+  device_pcg(Ctx *ctx, Comm *comm, double *S, size_t n, size_t n_dot, T *x, T *r, T *z, T *p, T *Ap, VMULT vmult, PRECOND precond, double reltol,
+             double abstol, unsigned maxiter, unsigned &n_iterations, double &residual)
+  {
+    const int g  = grid_for(n);
+    const int gd = std::min(g, 1024);
+    HIP_CHECK(hipMemsetAsync(x, 0, n * sizeof(T), ctx->stream));
+    dot_to_device(ctx, comm, S, r, r, n_dot, 3);
+    double       res  = std::sqrt(read_scalar(ctx, S, 3));
+    const double res0 = res;
+    n_iterations      = 0;
+    residual          = res;
+    if (res <= abstol)
+      return;
+    precond(z, r);
+    HIP_CHECK(hipMemcpyAsync(p, z, n * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
+    int cur = 0; // S[cur] = r.z
+    dot_to_device(ctx, comm, S, r, z, n_dot, cur);
+    for (unsigned it = 1; it <= maxiter; ++it)
+      {
+        vmult(Ap, p);
+        dot_to_device(ctx, comm, S, p, Ap, n_dot, 2);
+        hipLaunchKernelGGL(cg_update_xr_kernel<T>, gd, 256, 0, ctx->stream, x, r, p, Ap, n, n_dot, S, cur, ctx->d_partial);
+        hipLaunchKernelGGL(vec_dot_final_kernel, 1, 256, 0, ctx->stream, ctx->d_partial, gd, S + 3);
+        if (comm)
+          comm->allreduce_sum(S + 3, 1, MGAMD_F64, ctx->stream);
+        res          = std::sqrt(read_scalar(ctx, S, 3));
+        n_iterations = it;
+        residual     = res;
+        if (res < reltol * res0 || res <= abstol)
+          break;
+        precond(z, r);
+        dot_to_device(ctx, comm, S, r, z, n_dot, 1 - cur);
+        hipLaunchKernelGGL(cg_update_p_kernel<T>, g, 256, 0, ctx->stream, p, z, n, S, 1 - cur, cur);
+        cur = 1 - cur;
+      }
+    HIP_CHECK(hipGetLastError());
   }
 
   double
@@ -1529,9 +1595,11 @@ namespace mgamd
       return collapse_level;
     }
     DBuf<T>                          cg_r, cg_z, cg_p, cg_Ap;
+    DBuf<double>                     cg_S; // device scalars of the coarse CG (device_pcg)
     hipGraphExec_t                   graph_exec = nullptr;
     const void                      *graph_z = nullptr, *graph_r = nullptr;
 
+    uint64_t       coarse_iterations = 0; // inner CG iterations of the coarse solver, accumulated
     MultigridBase *nested   = nullptr; // coarse solver "gmg_vcycle"
     unsigned       n_cycles = 1;
 
@@ -1641,6 +1709,7 @@ namespace mgamd
           cg_z.alloc(n);
           cg_p.alloc(n);
           cg_Ap.alloc(n);
+          cg_S.alloc(8);
           if (coarse_type == "cg_with_chebyshev" && !sm[0])
             throw std::invalid_argument("multigrid: cg_with_chebyshev needs a smoother on level 0");
         }
@@ -1799,39 +1868,25 @@ namespace mgamd
     void
     coarse_cg(T *x, const T *b, bool with_cheb)
     {
-      // SolverCG + ReductionControl(maxiter 10000, abstol 1e-20, reltol 1e-4): ref:multigrid_throughput.cc:888-895
-      // (inner products over the GLOBAL vector: on a sharded level every DoF counts once, one scalar all-reduce each)
-      const size_t n = ops[0]->n_dofs();
-      const int    g = grid_for(n);
-      HIP_CHECK(hipMemsetAsync(x, 0, n * sizeof(T), ctx->stream));
+      // SolverCG + ReductionControl(maxiter 10000, abstol 1e-20, reltol 1e-4): ref:multigrid_throughput.cc:888-895;
+      // device-resident iteration, inner products over the GLOBAL vector (owned prefix + one scalar all-reduce on a
+      // sharded level)
+      LevelOperator<T> *op  = ops[0];
+      const size_t      n   = op->n_dofs();
+      const size_t      nd  = op->comm ? (size_t)op->tables->n_interior + op->tables->n_tail_owned : n;
       HIP_CHECK(hipMemcpyAsync(cg_r.p, b, n * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
-      const double res0 = std::sqrt(ops[0]->dot_raw_global(cg_r.p, cg_r.p));
-      if (res0 <= 1e-20)
-        return;
-      auto precond = [&]() {
-        if (with_cheb)
-          sm[0]->vmult_raw(cg_z.p, sm[0]->tmp.p, cg_r.p);
-        else
-          HIP_CHECK(hipMemcpyAsync(cg_z.p, cg_r.p, n * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
-      };
-      precond();
-      HIP_CHECK(hipMemcpyAsync(cg_p.p, cg_z.p, n * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
-      double rz = ops[0]->dot_raw_global(cg_r.p, cg_z.p);
-      for (unsigned it = 1; it <= 10000; ++it)
-        {
-          ops[0]->vmult_raw(cg_Ap.p, cg_p.p);
-          const double alpha = rz / ops[0]->dot_raw_global(cg_p.p, cg_Ap.p);
-          hipLaunchKernelGGL(vec_sadd_kernel<T>, g, 256, 0, ctx->stream, x, T(1), T(alpha), cg_p.p, n);
-          hipLaunchKernelGGL(vec_sadd_kernel<T>, g, 256, 0, ctx->stream, cg_r.p, T(1), T(-alpha), cg_Ap.p, n);
-          const double res = std::sqrt(ops[0]->dot_raw_global(cg_r.p, cg_r.p));
-          if (res < 1e-4 * res0 || res <= 1e-20)
-            break;
-          precond();
-          const double rz_new = ops[0]->dot_raw_global(cg_r.p, cg_z.p);
-          const double beta   = rz_new / rz;
-          rz                  = rz_new;
-          hipLaunchKernelGGL(vec_sadd_kernel<T>, g, 256, 0, ctx->stream, cg_p.p, T(beta), T(1), cg_z.p, n);
-        }
+      unsigned its = 0;
+      double   res = 0;
+      device_pcg<T>(
+        ctx, op->comm.get(), cg_S.p, n, nd, x, cg_r.p, cg_z.p, cg_p.p, cg_Ap.p, [&](T *Ap, const T *p) { op->vmult_raw(Ap, p); },
+        [&](T *z, const T *r) {
+          if (with_cheb)
+            sm[0]->vmult_raw(z, sm[0]->tmp.p, r);
+          else
+            HIP_CHECK(hipMemcpyAsync(z, r, n * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
+        },
+        1e-4, 1e-20, 10000, its, res);
+      coarse_iterations += its;
     }
 
     // the cycle on level vectors; defect[nl-1] must be set, coarser defects zero
@@ -2027,50 +2082,43 @@ namespace mgamd
   // ------------------------------------------------------------------------------------------
   // Outer solver: deal.II SolverCG + ReductionControl (ref:multigrid_throughput.cc:1140-1147,1625-1635)
   // ------------------------------------------------------------------------------------------
+  template <typename T>
+  static void
+  solve_cg_T(LevelOperatorBase &A, MultigridBase *M, mgamd_vec &x, const mgamd_vec &b, double reltol, double abstol, unsigned maxiter,
+             unsigned &n_iterations, double &residual)
+  {
+    Ctx         *ctx = A.ctx;
+    const size_t n   = A.n_dofs();
+    auto        *op  = static_cast<LevelOperator<T> *>(&A);
+    const size_t nd  = op->comm ? (size_t)op->tables->n_interior + op->tables->n_tail_owned : n;
+    std::unique_ptr<mgamd_vec> g(vec_create(ctx, n, A.type)), h(vec_create(ctx, n, A.type)), d(vec_create(ctx, n, A.type)),
+      Ad(vec_create(ctx, n, A.type));
+    vec_copy(*g, b); // residual r = b - A*0; dst = 0 (ref:multigrid_throughput.cc:1142,1245) is set by device_pcg
+    // the V-cycle works on whole vectors (it may alias them as level buffers): hand it the mgamd_vec objects
+    device_pcg<T>(
+      ctx, op->comm.get(), ctx->d_cg, n, nd, x.as<T>(), g->as<T>(), h->as<T>(), d->as<T>(), Ad->as<T>(), [&](T *Ap, const T *p) { op->vmult_raw(Ap, p); },
+      [&](T *z, const T *r) {
+        (void)z;
+        (void)r;
+        if (M)
+          M->vcycle(*h, *g);
+        else
+          vec_copy(*h, *g);
+      },
+      reltol, abstol, maxiter, n_iterations, residual);
+    ctx->sync();
+  }
+
   void
   solve_cg(LevelOperatorBase &A, MultigridBase *M, mgamd_vec &x, const mgamd_vec &b, double reltol, double abstol, unsigned maxiter,
            unsigned &n_iterations, double &residual)
   {
-    Ctx         *ctx = A.ctx;
-    const size_t n   = A.n_dofs();
+    const size_t n = A.n_dofs();
     if (x.n != n || b.n != n || x.type != A.type || b.type != A.type)
       throw std::invalid_argument("SolverCG::solve: bad vectors");
-    std::unique_ptr<mgamd_vec> g(vec_create(ctx, n, A.type)), h(vec_create(ctx, n, A.type)), d(vec_create(ctx, n, A.type)),
-      Ad(vec_create(ctx, n, A.type));
-    vec_set(x, 0.0); // dst = 0 (ref:multigrid_throughput.cc:1142,1245)
-    vec_copy(*g, b); // residual r = b - A*0
-    double res   = std::sqrt(A.dot(*g, *g));
-    const double res0 = res;
-    n_iterations = 0;
-    residual     = res;
-    if (res <= abstol)
-      return;
-    auto precond = [&]() {
-      if (M)
-        M->vcycle(*h, *g);
-      else
-        vec_copy(*h, *g);
-    };
-    precond();
-    vec_copy(*d, *h);
-    double gh = A.dot(*g, *h);
-    for (unsigned it = 1; it <= maxiter; ++it)
-      {
-        A.vmult(*Ad, *d);
-        const double alpha = gh / A.dot(*d, *Ad);
-        vec_sadd(x, 1.0, alpha, *d);
-        vec_sadd(*g, 1.0, -alpha, *Ad);
-        res          = std::sqrt(A.dot(*g, *g));
-        n_iterations = it;
-        residual     = res;
-        if (res < reltol * res0 || res <= abstol)
-          break;
-        precond();
-        const double gh_new = A.dot(*g, *h);
-        const double beta   = gh_new / gh;
-        gh                  = gh_new;
-        vec_sadd(*d, beta, 1.0, *h);
-      }
-    ctx->sync();
+    if (A.type == MGAMD_F64)
+      solve_cg_T<double>(A, M, x, b, reltol, abstol, maxiter, n_iterations, residual);
+    else
+      solve_cg_T<float>(A, M, x, b, reltol, abstol, maxiter, n_iterations, residual);
   }
 } // namespace mgamd

@@ -35,6 +35,7 @@ namespace mgamd
     double     *d_partial = nullptr; // 1024 block partials
     double     *d_result  = nullptr; // 8 scalars
     double     *h_result  = nullptr; // pinned
+    double     *d_cg      = nullptr; // 8 scalars of the device-resident CG (kernels.hpp)
     // dominant-kernel profiling (HIP events around the largest lattice_apply launches)
     bool                                           profile = false;
     int                                            prof_brick = 0; // 0: the dominant group of each level; B: groups of B^3 bricks only

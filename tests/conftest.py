@@ -13,6 +13,13 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu` on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    # a GPU test that loops (a solver that stops converging) must fail, not sit on the GPU box until the box is reclaimed
+    for item in items:
+        if item.get_closest_marker("gpu") is not None and item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(420, method="thread"))
+
+
 @pytest.fixture(scope="session")
 def mgamd():
     import dealii_multigrid_amd as m
