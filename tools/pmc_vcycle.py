@@ -1,0 +1,59 @@
+"""HBM traffic per kernel of the V-cycles between the markers of tools/vcycle_trace.py, from two rocprofv3 --pmc passes
+(FETCH_SIZE and WRITE_SIZE, collected separately as the MI355X guide prescribes).
+  python tools/pmc_vcycle.py <fetch counter_collection.csv> <write counter_collection.csv> <cycles> <out.json>
+gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports exactly 1/2 of the bytes of wide coalesced
+streaming reads -> doubled here; WRITE_SIZE is exact; both in KiB.  Calibrated in the same run on vec_sadd_kernel (reads 2
+words, writes 1 word per entry): the corrected numbers must give read/write = 2.0 and read = 16 B x n."""
+import csv, json, re, sys
+from collections import defaultdict
+
+MARK = 304 * 256
+
+
+def load(path):
+    rows = list(csv.DictReader(open(path)))
+    for r in rows:
+        if "Grid_Size" not in r:
+            r["Grid_Size"] = int(r["Grid_Size_X"])
+        r["Grid_Size"] = int(r["Grid_Size"])
+        r["Dispatch_Id"] = int(r["Dispatch_Id"])
+        r["Counter_Value"] = float(r["Counter_Value"])
+    rows.sort(key=lambda r: r["Dispatch_Id"])
+    return rows
+
+
+def window(rows):
+    mark = [i for i, r in enumerate(rows) if "vec_set_kernel" in r["Kernel_Name"] and r["Grid_Size"] == MARK]
+    assert len(mark) >= 2, "markers not found"
+    return rows[mark[-2] + 1:mark[-1]]
+
+
+def name(r):
+    return re.sub(r"\(.*", "", r["Kernel_Name"].replace("mgamd::", "").replace("void ", ""))
+
+
+fetch, write, cycles, out = load(sys.argv[1]), load(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+agg = defaultdict(lambda: [0.0, 0.0, 0])
+for r in window(fetch):
+    a = agg[(name(r), r["Grid_Size"] // 256)]
+    a[0] += r["Counter_Value"] * 1024 * 2
+    a[2] += 1
+for r in window(write):
+    agg[(name(r), r["Grid_Size"] // 256)][1] += r["Counter_Value"] * 1024
+cal_r = [r["Counter_Value"] * 2048 for r in fetch if "vec_sadd_kernel" in r["Kernel_Name"]]
+cal_w = [r["Counter_Value"] * 1024 for r in write if "vec_sadd_kernel" in r["Kernel_Name"]]
+rows = []
+for (k, g), (rd, wr, n) in sorted(agg.items(), key=lambda kv: -(kv[1][0] + kv[1][1])):
+    rows.append({"kernel": k, "workgroups": g, "launches_per_cycle": n / cycles, "read_bytes_per_launch": rd / n, "write_bytes_per_launch": wr / n,
+                 "hbm_bytes_per_launch": (rd + wr) / n, "hbm_bytes_per_cycle": (rd + wr) / cycles})
+tot = sum(r["hbm_bytes_per_cycle"] for r in rows)
+# the calibration dispatches of vcycle_trace.py are the largest vec_sadd launches of the run (32 M doubles)
+summary = {"note": __doc__, "cycles": cycles, "hbm_bytes_per_cycle_total": tot,
+           "calibration_vec_sadd": {"read_over_write": (max(cal_r) / max(cal_w)) if cal_r and cal_w else None,
+                                    "read_bytes": max(cal_r) if cal_r else None, "expected_read_bytes": 16.0 * (1 << 25),
+                                    "write_bytes": max(cal_w) if cal_w else None, "expected_write_bytes": 8.0 * (1 << 25)},
+           "kernels": rows}
+json.dump(summary, open(out, "w"), indent=1)
+print(f"HBM bytes per cycle: {tot/1e9:.3f} GB; calibration {summary['calibration_vec_sadd']}")
+for r in rows[:14]:
+    print(f'{r["kernel"][:60]:60s} wgs {r["workgroups"]:7d} x{r["launches_per_cycle"]:4.1f}  read {r["read_bytes_per_launch"]/1e6:9.1f} MB write {r["write_bytes_per_launch"]/1e6:9.1f} MB')

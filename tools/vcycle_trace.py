@@ -18,6 +18,12 @@ h = m.Hierarchy(ctx, geo, L, p, mg_type, coarse_solver="amg" if mg_type == "HMG-
 b, z = h.fine_operator.initialize_dof_vector(), h.fine_operator.initialize_dof_vector()
 h.fine_operator.rhs(b)
 marker = m.Vector(ctx, MARKER_N)
+# calibration dispatches for the PMC summaries (tools/pmc_vcycle.py): y = s y + a x on 32 M doubles reads 2 words and
+# writes 1 word per entry
+ca, cb = m.Vector(ctx, 1 << 25), m.Vector(ctx, 1 << 25)
+ca.set(1.0), cb.set(2.0)
+for _ in range(3):
+    ca.sadd(0.5, 0.25, cb)
 for _ in range(3):
     h.mg.vmult(z, b)
 ctx.synchronize()
