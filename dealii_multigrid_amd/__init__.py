@@ -74,6 +74,7 @@ class DofsInfo(C.Structure):
         ("n_hanging_owned", C.c_uint32),
         ("n_peers", C.c_uint32),
         ("n_halo_send", C.c_uint32),
+        ("n_edge", C.c_uint32),
     ]
 
 
@@ -91,6 +92,12 @@ class Triangulation:
         nc, nl, nh = C.c_uint64(), C.c_uint32(), C.c_uint64()
         _chk(_lib.mgamd_tria_info(self._h, C.byref(nc), C.byref(nl), C.byref(nh)))
         self.n_cells, self.n_levels, self.n_cells_hn = nc.value, nl.value, nh.value
+
+    def level_mesh(self, level: int) -> "Triangulation":
+        """local smoothing: all cells of refinement level `level`, active or not (distribute_mg_dofs levels)"""
+        h = C.c_void_p()
+        _chk(_lib.mgamd_tria_level_mesh(self._h, level, C.byref(h)))
+        return Triangulation(_handle=h)
 
     def coarsen(self) -> "Triangulation":
         h = C.c_void_p()
@@ -152,10 +159,14 @@ class Partition:
 
 
 class DoFs:
-    def __init__(self, tria: Triangulation, degree: int, max_brick: int = 0, partition: "Partition" = None, level: int = 0, rank: int = 0):
+    def __init__(self, tria: Triangulation, degree: int, max_brick: int = 0, partition: "Partition" = None, level: int = 0, rank: int = 0,
+                 local_smoothing_level: bool = False):
+        """local_smoothing_level: `tria` is Triangulation.level_mesh(l); refinement-edge DoFs are numbered [I | T | E | D | H]"""
         self.tria = tria
         self._h = C.c_void_p()
-        if partition is None:
+        if local_smoothing_level:
+            _chk(_lib.mgamd_dofs_create_level(tria._h, degree, max_brick, C.byref(self._h)))
+        elif partition is None:
             _chk(_lib.mgamd_dofs_create(tria._h, degree, max_brick, C.byref(self._h)))
         else:
             _chk(_lib.mgamd_dofs_create_local(partition._h, level, rank, degree, max_brick, C.byref(self._h)))
@@ -223,6 +234,16 @@ class DoFs:
         if getattr(self, "_h", None):
             _lib.mgamd_dofs_destroy(self._h)
             self._h = None
+
+
+def ls_copy_indices(active: DoFs, level_dofs: DoFs, level: int):
+    """copy_to_mg / copy_from_mg index pairs (active-mesh index, level index) of refinement level `level`"""
+    n = C.c_uint64()
+    _chk(_lib.mgamd_ls_copy_indices(active._h, level_dofs._h, level, C.byref(n), None, None))
+    g, l = np.zeros(n.value, np.uint32), np.zeros(n.value, np.uint32)
+    if n.value:
+        _chk(_lib.mgamd_ls_copy_indices(active._h, level_dofs._h, level, C.byref(n), _ptr(g), _ptr(l)))
+    return g, l
 
 
 def transfer_tables(fine: DoFs, coarse: DoFs):
@@ -401,6 +422,10 @@ class Operator:
     def vmult(self, dst: Vector, src: Vector):
         _chk(_lib.mgamd_level_op_vmult(self._h, dst._h, src._h))
 
+    def vmult_interface_up(self, dst: Vector, src: Vector):
+        """local-smoothing level: the edge matrix, A with the refinement-edge DoFs unconstrained applied to src|edge"""
+        _chk(_lib.mgamd_level_op_vmult_interface_up(self._h, dst._h, src._h))
+
     def compute_inverse_diagonal(self, diagonal: Vector):
         _chk(_lib.mgamd_level_op_inverse_diagonal(self._h, diagonal._h))
 
@@ -468,16 +493,19 @@ class PreconditionMG:
     """Multigrid<Vector> + PreconditionMG over MGTransferGlobalCoarsening."""
 
     def __init__(self, ctx: Context, levels, transfers, smoothers, coarse_solver="direct", nested: "PreconditionMG" = None,
-                 n_cycles: int = 1):
+                 n_cycles: int = 1, local_smoothing: "DoFs" = None):
         """nested: geometric stand-in for the AMG coarse solvers on a large coarse level (an h-multigrid whose finest level
-        is levels[0]), applied n_cycles times per coarse solve; see mgamd.h"""
+        is levels[0]), applied n_cycles times per coarse solve; see mgamd.h.
+        local_smoothing: the DoFs of the ACTIVE mesh; `levels` are then operators on the refinement levels (HMG-local)"""
         self.ctx, self.levels, self.transfers, self.smoothers, self.nested = ctx, levels, transfers, smoothers, nested
         n = len(levels)
         L = (C.c_void_p * n)(*[l._h for l in levels])
         T = (C.c_void_p * n)(*[(t._h if t is not None else None) for t in transfers])
         S = (C.c_void_p * n)(*[(s._h if s is not None else None) for s in smoothers])
         self._h = C.c_void_p()
-        if nested is None:
+        if local_smoothing is not None:
+            _chk(_lib.mgamd_mg_create_local_smoothing(ctx._h, n, L, T, S, local_smoothing._h, coarse_solver.encode(), C.byref(self._h)))
+        elif nested is None:
             _chk(_lib.mgamd_mg_create(ctx._h, n, L, T, S, coarse_solver.encode(), C.byref(self._h)))
         else:
             _chk(_lib.mgamd_mg_create_nested(ctx._h, n, L, T, S, coarse_solver.encode(), nested._h, n_cycles, C.byref(self._h)))
@@ -576,6 +604,10 @@ class Hierarchy:
             hseq = create_geometric_coarsening_sequence(fine)
             self.trias = hseq + [fine] * (len(pseq) - 1)
             self.degrees = [pseq[0]] * len(hseq) + pseq[1:]
+        elif mg_type == "HMG-local":
+            self._build_local_smoothing(ctx, fine, degree, smoother_degree, smoothing_range, eig_cg_n_iterations, coarse_solver, number_type,
+                                        max_brick)
+            return
         else:
             raise MgamdError(f"Type '{mg_type}' not implemented")
         # max_brick=-1: bricks on large levels, single-cell slots on the latency-bound small ones (level_tables.hpp)
@@ -592,6 +624,26 @@ class Hierarchy:
                                  self.coarse.mg if self.coarse else None, coarse_n_cycles)
         self.fine_operator = self.operators[-1] if number_type == F64 else Operator(ctx, self.dofs[-1], F64)
         self.n_dofs = self.dofs[-1].n_dofs
+
+
+def _hierarchy_build_local_smoothing(self, ctx, fine, degree, smoother_degree, smoothing_range, eig_cg_n_iterations, coarse_solver,
+                                     number_type, max_brick):
+    """solve_with_local_smoothing (ref:multigrid_throughput.cc:1670-1873): operators on the refinement levels 0..L of the
+    octree, MGTransferMatrixFree between them, edge matrices, the outer operator on the active mesh"""
+    self.active_dofs = DoFs(fine, degree, max_brick)
+    self.trias = [fine.level_mesh(l) for l in range(fine.n_levels)]
+    self.degrees = [degree] * len(self.trias)
+    self.dofs = [DoFs(t, degree, max_brick, local_smoothing_level=True) for t in self.trias]
+    self.operators = [Operator(ctx, d, number_type) for d in self.dofs]
+    self.transfers = [None] + [MGTwoLevelTransfer(self.operators[l], self.operators[l - 1]) for l in range(1, len(self.dofs))]
+    self.smoothers = [PreconditionChebyshev(op, smoother_degree, smoothing_range, eig_cg_n_iterations) for op in self.operators]
+    self.coarse = None
+    self.mg = PreconditionMG(ctx, self.operators, self.transfers, self.smoothers, coarse_solver, local_smoothing=self.active_dofs)
+    self.fine_operator = Operator(ctx, self.active_dofs, F64)
+    self.n_dofs = self.active_dofs.n_dofs
+
+
+Hierarchy._build_local_smoothing = _hierarchy_build_local_smoothing
 
 
 class DistributedHierarchy:

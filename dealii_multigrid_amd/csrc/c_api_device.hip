@@ -559,6 +559,48 @@ mgamd_mg_create_nested(mgamd_ctx *ctx, unsigned n_levels, mgamd_level_op *const 
 }
 
 int
+mgamd_mg_create_local_smoothing(mgamd_ctx *ctx, unsigned n_levels, mgamd_level_op *const *levels, mgamd_transfer2 *const *transfers,
+                                mgamd_cheb *const *smoothers, const mgamd_dofs *active_mesh_dofs, const char *coarse_solver, mgamd_mg **out)
+{
+  MGAMD_TRY
+  REQUIRE(ctx && levels && out && active_mesh_dofs && n_levels > 0 && (n_levels == 1 || (transfers && smoothers)));
+  std::vector<LevelOperatorBase *> L(n_levels, nullptr);
+  std::vector<Transfer2Base *>     Tr(n_levels, nullptr);
+  std::vector<ChebyshevBase *>     Sm(n_levels, nullptr);
+  for (unsigned l = 0; l < n_levels; ++l)
+    {
+      REQUIRE(levels[l]);
+      L[l] = levels[l]->op.get();
+      if (transfers && transfers[l])
+        Tr[l] = transfers[l]->t.get();
+      if (smoothers && smoothers[l])
+        Sm[l] = smoothers[l]->c.get();
+    }
+  auto *h = new mgamd_mg;
+  try
+    {
+      h->mg.reset(make_multigrid(ctx->ctx.get(), n_levels, L.data(), Tr.data(), Sm.data(), coarse_solver ? coarse_solver : "amg"));
+      h->mg->setup_local_smoothing(*active_mesh_dofs->tables);
+    }
+  catch (...)
+    {
+      delete h;
+      throw;
+    }
+  *out = h;
+  MGAMD_CATCH
+}
+
+int
+mgamd_level_op_vmult_interface_up(mgamd_level_op *op, mgamd_vec *dst, const mgamd_vec *src)
+{
+  MGAMD_TRY
+  REQUIRE(op && dst && src);
+  op->op->vmult_interface_up(*dst, *src);
+  MGAMD_CATCH
+}
+
+int
 mgamd_mg_set_collapse(mgamd_mg *mg, int enable, unsigned *collapse_level)
 {
   MGAMD_TRY

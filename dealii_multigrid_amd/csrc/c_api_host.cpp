@@ -145,11 +145,68 @@ mgamd_dofs_info(const mgamd_dofs *d, mgamd_dofs_info_t *info)
   info->n_hanging_owned   = L.n_hanging_owned;
   info->n_peers           = d->halo ? (uint32_t)d->halo->peers.size() : 0;
   info->n_halo_send       = d->halo ? (uint32_t)d->halo->pack_idx.size() : 0;
+  info->n_edge            = L.n_edge;
   for (size_t g = 0; g < L.groups.size() && g < 8; ++g)
     {
       info->group_B[g]     = L.groups[g].B;
       info->group_slots[g] = L.groups[g].n_slots();
     }
+  MGAMD_CATCH
+}
+
+int
+mgamd_tria_level_mesh(const mgamd_tria *fine, unsigned level, mgamd_tria **out)
+{
+  MGAMD_TRY
+  if (!fine || !out)
+    throw std::invalid_argument("null argument");
+  if ((int)level >= fine->tria->n_levels())
+    throw std::invalid_argument("level_mesh: the mesh has no cells on that refinement level");
+  auto *t = new mgamd_tria;
+  t->tria = std::make_shared<Tria>(fine->tria->level_mesh((int)level));
+  *out    = t;
+  MGAMD_CATCH
+}
+
+int
+mgamd_dofs_create_level(const mgamd_tria *level_mesh, int degree, int max_brick, mgamd_dofs **out)
+{
+  MGAMD_TRY
+  if (!level_mesh || !out)
+    throw std::invalid_argument("null argument");
+  if (degree < 1 || degree > MAX_DEGREE)
+    throw std::invalid_argument("degree must be in [1," + std::to_string(MAX_DEGREE) + "]");
+  auto *d = new mgamd_dofs;
+  d->tria = level_mesh->tria;
+  try
+    {
+      d->tables = std::make_shared<LevelTables>(*d->tria, degree, std::max(max_brick, 0), nullptr, false, nullptr, 0, true);
+      if (max_brick < 0 && is_small_level(d->tria->n_cells(), degree) && n_nonempty_groups(*d->tables) > 1)
+        d->tables = std::make_shared<LevelTables>(*d->tria, degree, 1, nullptr, false, nullptr, 0, true);
+    }
+  catch (...)
+    {
+      delete d;
+      throw;
+    }
+  *out = d;
+  MGAMD_CATCH
+}
+
+int
+mgamd_ls_copy_indices(const mgamd_dofs *active_mesh_dofs, const mgamd_dofs *level_dofs, unsigned level, uint64_t *count, uint32_t *global_idx,
+                      uint32_t *level_idx)
+{
+  MGAMD_TRY
+  if (!active_mesh_dofs || !level_dofs || !count)
+    throw std::invalid_argument("null argument");
+  std::vector<uint32_t> g, l;
+  ls_copy_indices(*active_mesh_dofs->tables, *level_dofs->tables, (int)level, g, l);
+  *count = g.size();
+  if (global_idx)
+    std::copy(g.begin(), g.end(), global_idx);
+  if (level_idx)
+    std::copy(l.begin(), l.end(), level_idx);
   MGAMD_CATCH
 }
 

@@ -655,6 +655,11 @@ namespace mgamd
     unsigned long long *stamps; // debug only (MGAMD_STAMPS): 8 wall-clock stamps per workgroup, nullptr normally
     uint32_t     ablate; // debug only (MGAMD_ABLATE): 1 no sweeps, 2 no shell atomics, 4 no interior epilogue, 8 no interior gather, 16 no shell gather
     Epilogue<T>  epi;
+    // shell entries are gathered if their index is below gather_limit and receive partial sums if it is below
+    // scatter_limit.  Dirichlet entries are DEV_INVALID (above every limit).  Local-smoothing levels number their
+    // refinement-edge DoFs right after the tail: the level operator keeps them out (both limits = first edge index), the
+    // residual scatters to their rows, the edge matrix gathers and scatters them (runtime.hip, EdgeMode).
+    uint32_t gather_limit, scatter_limit;
   };
 
   // Interior-slot bookkeeping shared by the gather and the epilogue of lattice_apply_kernel: thread `tid`
@@ -824,7 +829,7 @@ namespace mgamd
 #pragma unroll
             for (int it = 0; it < ITERS; ++it)
               {
-                const uint32_t gi = sgi[it] != DEV_INVALID ? sgi[it] : 0;
+                const uint32_t gi = sgi[it] < args.gather_limit ? sgi[it] : 0;
                 sval[it]          = args.epi.dinv[gi];
                 sb[it]            = args.epi.b[gi];
               }
@@ -836,7 +841,7 @@ namespace mgamd
           {
 #pragma unroll
             for (int it = 0; it < ITERS; ++it)
-              sval[it] = args.src[sgi[it] != DEV_INVALID ? sgi[it] : 0];
+              sval[it] = args.src[sgi[it] < args.gather_limit ? sgi[it] : 0];
           }
       }
     // D^-1 of this thread's interior entry `it` (see above); looked up where needed, never held in registers
@@ -880,7 +885,7 @@ namespace mgamd
 #pragma unroll
         for (int it = 0; it < ITERS; ++it)
           if (spos[it] >= 0)
-            bufA[spos[it]] = sgi[it] != DEV_INVALID ? sval[it] : T(0);
+            bufA[spos[it]] = sgi[it] < args.gather_limit ? sval[it] : T(0);
       }
     if (G::N_INT > 0 && !MGAMD_ABLATED(8))
       {
@@ -957,7 +962,7 @@ namespace mgamd
       {
 #pragma unroll
         for (int it = 0; it < ITERS; ++it)
-          if (spos[it] >= 0 && sgi[it] != DEV_INVALID)
+          if (spos[it] >= 0 && sgi[it] < args.scatter_limit)
             atomic_add(&args.tail_acc[sgi[it] - args.n_interior], bufA[spos[it]]);
       }
 #ifdef MGAMD_KERNEL_DEBUG
@@ -1360,7 +1365,7 @@ namespace mgamd
       {
         const int      sl2 = idx / G::N_SHELL, s = idx % G::N_SHELL;
         const uint32_t gi  = args.g.shell_idx[(size_t)(slot0 + sl2) * G::N_SHELL + s];
-        if (gi != DEV_INVALID)
+        if (gi < args.scatter_limit)
           atomic_add(&args.tail_acc[gi - args.n_interior], bufD[sl2 * G::N3 + args.g.shell_pos[s]]);
       }
   }
@@ -2261,6 +2266,20 @@ namespace mgamd
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_shared; i += stride)
       if (sh_owner_src[i] >= 0)
         tail[sh_tail[i]] = recv[sh_owner_src[i]];
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // Local smoothing: copy_to_mg / copy_from_mg between the active-mesh vector and a level vector (index pairs of
+  // LevelTables / ls_copy_indices), with the cast between the outer and the level number type
+  // ------------------------------------------------------------------------------------------
+  template <typename TD, typename TS>
+  __global__ void
+  __launch_bounds__(256) indexed_copy_kernel(TD *__restrict__ dst, const uint32_t *__restrict__ dst_idx, const TS *__restrict__ src,
+                                             const uint32_t *__restrict__ src_idx, uint32_t n)
+  {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+      dst[dst_idx[i]] = (TD)src[src_idx[i]];
   }
 
   // ------------------------------------------------------------------------------------------

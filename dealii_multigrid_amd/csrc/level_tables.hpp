@@ -315,6 +315,16 @@ namespace mgamd
     FE1D                   fe;
     std::vector<SlotGroup> groups; // one per brick size, largest first; last = single cells
     uint32_t               n_dofs = 0, n_interior = 0, n_tail = 0, n_dirichlet = 0, n_hanging = 0;
+    // Local smoothing (`HMG-local`): a LEVEL of the refinement hierarchy = all cells of one refinement level, which cover
+    // only part of the domain.  The DoFs on the boundary of that region which are not on the domain boundary are the
+    // REFINEMENT-EDGE DoFs (MGTools::extract_inner_interface_dofs, ref:include/operator.h:49-70,539-556): numbered
+    // [ I | T | E | D | H ].  The level operator treats E like D (zero input, identity row); the edge matrices treat them
+    // like T.  Their shell entries keep the real index: the kernels compare it with a gather / scatter LIMIT (D entries
+    // are INVALID = 0xFFFFFFFF, above every limit).
+    bool     ls_level = false;
+    uint32_t n_edge   = 0;
+    static constexpr int      CLS_SHIFT = 29;
+    static constexpr uint32_t CLS_MASK  = (1u << CLS_SHIFT) - 1;
     // distributed runs: the tail is [owned | copies of DoFs owned by a lower rank]; *_owned count each DoF once globally
     uint32_t n_tail_owned = 0, n_dirichlet_owned = 0, n_hanging_owned = 0;
     // Pipelined operator pass (runtime.hip): the slots of the group with the most work
@@ -332,14 +342,17 @@ namespace mgamd
 
     // owned: optional per-cell flags (distributed runs: this rank's cells); shared: key -> mask of other sharing ranks
     LevelTables(const Tria &t, int degree, int max_brick = 0, const std::vector<uint8_t> *owned = nullptr, bool helpers_only = false,
-                const std::map<uint64_t, SharedInfo> *shared = nullptr, int my_rank = 0)
+                const std::map<uint64_t, SharedInfo> *shared = nullptr, int my_rank = 0, bool local_smoothing_level = false)
       : p(degree)
       , tria(&t)
       , fe(degree)
+      , ls_level(local_smoothing_level)
       , owned(owned)
       , shared(shared)
       , my_rank(my_rank)
     {
+      if (ls_level && (owned || shared))
+        throw std::runtime_error("local-smoothing levels are not sharded in this build");
       if (!helpers_only)
         build(max_brick > 0 ? std::min(max_brick, max_brick_for_degree(p)) : max_brick_for_degree(p));
     }
@@ -352,7 +365,12 @@ namespace mgamd
     uint32_t
     first_constrained() const
     {
-      return n_interior + n_tail;
+      return n_interior + n_tail; // refinement-edge DoFs count as constrained for the level operator
+    }
+    uint32_t
+    first_dirichlet() const
+    {
+      return n_interior + n_tail + n_edge;
     }
 
     // is local node (a,b,c) of a masked cell on one of its hanging faces/edges?
@@ -426,7 +444,7 @@ namespace mgamd
           if (!idx)
             throw std::runtime_error("constrained family: parent DoF not numbered");
           const uint32_t gi = (uint32_t)*idx;
-          return (gi >= n_interior + n_tail && gi < n_interior + n_tail + n_dirichlet) ? INVALID_DOF : gi;
+          return (gi >= first_dirichlet() && gi < first_dirichlet() + n_dirichlet) ? INVALID_DOF : gi;
         }
       const int x = (c.i & (g.B - 1)) * p + a[0], y = (c.j & (g.B - 1)) * p + a[1], z = (c.k & (g.B - 1)) * p + a[2];
       const int N = g.N;
@@ -693,7 +711,7 @@ namespace mgamd
                   if (!key_on_boundary(key))
                     continue;
                   const int32_t *gi = keymap.find(key);
-                  if (gi && (uint32_t)*gi >= n_interior + n_tail && (uint32_t)*gi < n_interior + n_tail + n_dirichlet)
+                  if (gi && (uint32_t)*gi >= first_dirichlet() && (uint32_t)*gi < first_dirichlet() + n_dirichlet)
                     {
                       double pos[3];
                       gathered_node_position(ci, a, pos);
@@ -872,7 +890,36 @@ namespace mgamd
       n_interior = (uint32_t)next;
       // ---- 3. shell DoFs: class 0 tail, 1 Dirichlet, 2 hanging; provisional id = (class<<30 | counter)
       keymap.erase_all_and_reserve(1024);
-      uint32_t counter[4] = {0, 0, 0, 0}; // 0 tail (owned), 1 Dirichlet, 2 hanging, 3 tail copy of a lower rank's DoF
+      // local smoothing: keys of the DoFs on faces of level cells whose neighbour position is inside the domain but not
+      // covered by a cell of this level
+      FlatMap edge_keys;
+      edge_keys.erase_all_and_reserve(1024);
+      if (ls_level)
+        for (size_t ci = 0; ci < nc; ++ci)
+          {
+            const Cell   &c     = cells[ci];
+            const int64_t n1    = (int64_t)1 << c.level;
+            const int64_t id[3] = {c.i, c.j, c.k};
+            for (int d = 0; d < 3; ++d)
+              for (int side = 0; side < 2; ++side)
+                {
+                  int64_t nb[3] = {id[0], id[1], id[2]};
+                  nb[d] += side ? 1 : -1;
+                  if (nb[d] < 0 || nb[d] >= n1 || tria->find_leaf(c.level, nb[0], nb[1], nb[2]) >= 0)
+                    continue;
+                  const int e = (d + 1) % 3, f = (d + 2) % 3;
+                  for (int ae = 0; ae <= p; ++ae)
+                    for (int af = 0; af <= p; ++af)
+                      {
+                        int a[3];
+                        a[d] = side * p;
+                        a[e] = ae;
+                        a[f] = af;
+                        edge_keys.insert(own_key(c, a), 1);
+                      }
+                }
+          }
+      uint32_t counter[5] = {0, 0, 0, 0, 0}; // 0 tail (owned), 1 Dirichlet, 2 hanging, 3 tail copy of a lower rank's DoF, 4 refinement edge
       uint32_t n_copy_d = 0, n_copy_h = 0;
       auto     classify = [&](uint64_t key, int cls) -> int32_t {
         bool     ins;
@@ -892,7 +939,7 @@ namespace mgamd
                       ++n_copy_h;
                   }
               }
-            *v = (int32_t)(((uint32_t)cls << 30) | counter[cls]++);
+            *v = (int32_t)(((uint32_t)cls << CLS_SHIFT) | counter[cls]++);
             key_list.push_back(key);
           }
         return *v;
@@ -936,7 +983,7 @@ namespace mgamd
                 }
               else
                 key = own_key(anchor, a);
-              const int32_t id = classify(key, key_on_boundary(key) ? 1 : 0);
+              const int32_t id = classify(key, key_on_boundary(key) ? 1 : ((ls_level && edge_keys.find(key)) ? 4 : 0));
               g.shell_idx[(size_t)r.slot * g.n_shell + s] = (uint32_t)id; // provisional
             }
         }
@@ -998,16 +1045,16 @@ namespace mgamd
                 for (int s = 0; s < g.n_shell; ++s)
                   {
                     const uint32_t v = g.shell_idx[(size_t)r.slot * g.n_shell + s];
-                    if (v != INVALID_DOF && (v >> 30) == 0)
-                      stage[v & 0x3FFFFFFFu] = std::max(stage[v & 0x3FFFFFFFu], st);
+                    if (v != INVALID_DOF && (v >> CLS_SHIFT) == 0)
+                      stage[v & CLS_MASK] = std::max(stage[v & CLS_MASK], st);
                   }
               }
             if (shared) // the partial sums of DoFs on inter-rank interfaces are completed by the halo exchange first
               for (size_t t = 0; t < key_list.size(); ++t)
                 {
                   const uint32_t v = (uint32_t)*keymap.find(key_list[t]);
-                  if ((v >> 30) == 0 && shared->find(key_list[t]) != shared->end())
-                    stage[v & 0x3FFFFFFFu] = (uint8_t)C;
+                  if ((v >> CLS_SHIFT) == 0 && shared->find(key_list[t]) != shared->end())
+                    stage[v & CLS_MASK] = (uint8_t)C;
                 }
             std::vector<uint32_t> count(C + 2, 0);
             for (uint8_t st : stage)
@@ -1024,16 +1071,18 @@ namespace mgamd
       n_tail            = counter[0] + counter[3];
       n_dirichlet       = counter[1];
       n_hanging         = counter[2];
+      n_edge            = counter[4];
       n_dirichlet_owned = n_dirichlet - n_copy_d;
       n_hanging_owned   = n_hanging - n_copy_h;
-      const uint64_t total = (uint64_t)n_interior + n_tail + n_dirichlet + n_hanging;
+      const uint64_t total = (uint64_t)n_interior + n_tail + n_edge + n_dirichlet + n_hanging;
       if (total > 0xFFFFFFF0ull)
         throw std::runtime_error("level exceeds 32-bit DoF indices");
       n_dofs                 = (uint32_t)total;
-      const uint32_t base[4] = {n_interior, n_interior + n_tail, n_interior + n_tail + n_dirichlet, n_interior + n_tail_owned};
+      const uint32_t base[5] = {n_interior, n_interior + n_tail + n_edge, n_interior + n_tail + n_edge + n_dirichlet, n_interior + n_tail_owned,
+                                n_interior + n_tail};
       auto           final_index = [&](uint32_t prov) {
-        const uint32_t c = prov & 0x3FFFFFFFu;
-        return base[prov >> 30] + (((prov >> 30) == 0 && !tail_perm.empty()) ? tail_perm[c] : c);
+        const uint32_t c = prov & CLS_MASK;
+        return base[prov >> CLS_SHIFT] + (((prov >> CLS_SHIFT) == 0 && !tail_perm.empty()) ? tail_perm[c] : c);
       };
       key_index.resize(key_list.size());
       for (size_t t = 0; t < key_list.size(); ++t)
@@ -1044,7 +1093,7 @@ namespace mgamd
         }
       for (SlotGroup &g : groups)
         for (uint32_t &v : g.shell_idx)
-          v = (v == INVALID_DOF || (v >> 30) == 1) ? INVALID_DOF : final_index(v);
+          v = (v == INVALID_DOF || (v >> CLS_SHIFT) == 1) ? INVALID_DOF : final_index(v);
     }
   };
 } // namespace mgamd

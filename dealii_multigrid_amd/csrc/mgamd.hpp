@@ -52,6 +52,17 @@ namespace mgamd
       r->query();
       return r;
     }
+    // local smoothing: all cells of refinement level `level`, active or not (the level of DoFHandler::distribute_mg_dofs)
+    std::shared_ptr<Triangulation>
+    level_mesh(unsigned level) const
+    {
+      mgamd_tria *t = nullptr;
+      check(mgamd_tria_level_mesh(h.get(), level, &t));
+      auto r = std::shared_ptr<Triangulation>(new Triangulation());
+      r->h.reset(t, mgamd_tria_destroy);
+      r->query();
+      return r;
+    }
     uint64_t
     n_global_active_cells() const
     {
@@ -108,11 +119,16 @@ namespace mgamd
   class DoFHandler
   {
   public:
-    DoFHandler(const std::shared_ptr<const Triangulation> &tria, unsigned fe_degree, int max_brick = -1)
+    // mg_level = true: `tria` is Triangulation::level_mesh(l): the level DoFs of distribute_mg_dofs with the refinement-edge
+    // set of MGConstrainedDoFs
+    DoFHandler(const std::shared_ptr<const Triangulation> &tria, unsigned fe_degree, int max_brick = -1, bool mg_level = false)
       : tria(tria)
     {
       mgamd_dofs *d = nullptr;
-      check(mgamd_dofs_create(tria->get(), (int)fe_degree, max_brick, &d));
+      if (mg_level)
+        check(mgamd_dofs_create_level(tria->get(), (int)fe_degree, max_brick, &d));
+      else
+        check(mgamd_dofs_create(tria->get(), (int)fe_degree, max_brick, &d));
       h.reset(d, mgamd_dofs_destroy);
       check(mgamd_dofs_info(h.get(), &info));
     }
@@ -374,11 +390,13 @@ namespace mgamd
   {
   public:
     using StageSlot = std::function<void(bool /*start*/, unsigned /*level*/)>;
+    // active_mesh_dofs: local smoothing (solve_with_local_smoothing, ref:multigrid_throughput.cc:1670-1873): mg_matrices are the
+    // operators on the refinement levels (DoFHandler with mg_level = true), vmult acts on vectors of the active mesh.
     // coarse_mg: the geometric stand-in for the AMG coarse solvers on a large coarse level (an h-multigrid whose finest level
     // is mg_matrices[0]), applied n_cycles times per coarse solve
     PreconditionMG(const Context &ctx, const std::vector<Operator> &mg_matrices, const std::vector<MGTwoLevelTransfer> &transfers,
                    const std::vector<PreconditionChebyshev> &smoothers, const std::string &coarse_grid_solver_type,
-                   const PreconditionMG *coarse_mg = nullptr, unsigned n_cycles = 1)
+                   const PreconditionMG *coarse_mg = nullptr, unsigned n_cycles = 1, const DoFHandler *active_mesh_dofs = nullptr)
     {
       const unsigned                 n = mg_matrices.size();
       std::vector<mgamd_level_op *>  L(n);
@@ -392,7 +410,10 @@ namespace mgamd
             T[l] = transfers[l].get();
         }
       mgamd_mg *m = nullptr;
-      if (coarse_mg)
+      if (active_mesh_dofs)
+        check(mgamd_mg_create_local_smoothing(ctx.get(), n, L.data(), T.data(), S.data(), active_mesh_dofs->get(),
+                                              coarse_grid_solver_type.c_str(), &m));
+      else if (coarse_mg)
         {
           check(mgamd_mg_create_nested(ctx.get(), n, L.data(), T.data(), S.data(), coarse_grid_solver_type.c_str(), coarse_mg->get(),
                                        n_cycles, &m));

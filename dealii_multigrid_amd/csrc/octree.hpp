@@ -186,6 +186,25 @@ namespace mgamd
     from_cells(std::vector<Cell> leaves); // must be a balanced partition of the cube
     Tria
     coarsen_global() const; // one level of the geometric coarsening sequence
+    // local smoothing: ALL cells of refinement level `level`, active or not (DoFHandler::distribute_mg_dofs levels)
+    Tria
+    level_mesh(int level) const
+    {
+      std::vector<Cell> out;
+      FlatMap           seen;
+      seen.erase_all_and_reserve(cells.size());
+      for (const Cell &c : cells)
+        if (c.level >= level)
+          {
+            const int  s = c.level - level;
+            const Cell a{c.i >> s, c.j >> s, c.k >> s, (uint8_t)level};
+            bool       ins;
+            seen.insert(cell_key(a), 1, &ins);
+            if (ins)
+              out.push_back(a);
+          }
+      return from_cells(std::move(out));
+    }
 
     size_t
     n_cells() const

@@ -495,8 +495,8 @@ namespace mgamd
               d->shell_pos.upload(g.shell_pos);
               if (std::any_of(g.fmask.begin(), g.fmask.end(), [](uint32_t m) { return m != 0; }))
                 d->fmask.upload(g.fmask);
-              if (p == 1 && g.B == 1 && !getenv("MGAMD_NO_CELL_CLUSTERS"))
-                d->build_clusters(g);
+              if (p == 1 && g.B == 1 && !getenv("MGAMD_NO_CELL_CLUSTERS") && !tables->ls_level)
+                d->build_clusters(g); // (the cluster tables bake in which nodes are constrained: not on local-smoothing levels)
             }
           const size_t work = d->n_slots * (size_t)g.N * g.N * g.N;
           if (work > best)
@@ -519,7 +519,7 @@ namespace mgamd
           stamps.alloc(nwg * 8 + 8);
           stamps.zero(ctx->stream);
         }
-      tail_acc.alloc(std::max<uint32_t>(tables->n_tail, 1));
+      tail_acc.alloc(std::max<uint32_t>(tables->n_tail + tables->n_edge, 1));
       tail_acc.zero(ctx->stream);
     }
 
@@ -694,7 +694,7 @@ namespace mgamd
     void
     launch_tail(hipStream_t st, uint32_t begin, uint32_t end, bool with_rest, const Epilogue<T> &epi, bool diag)
     {
-      const uint32_t n_rest = with_rest ? tables->n_dofs - tables->n_interior - tables->n_tail : 0;
+      const uint32_t n_rest = with_rest ? tables->n_dofs - tables->n_interior - end : 0;
       const uint32_t n_t    = end - begin + n_rest;
       if (!n_t)
         return;
@@ -712,11 +712,27 @@ namespace mgamd
     // that are complete after that chunk (LevelTables::tail_stage_end) run on the side queue underneath the next chunks.
     // The brick kernel is latency-bound (2 workgroups per CU, sweeps between the memory phases), the tail epilogue is a
     // pure stream without LDS: they share the CUs instead of running one after the other.
+    // Refinement-edge DoFs of a local-smoothing level (LevelTables::n_edge, numbered right after the tail):
+    //   EDGE_OUT   the level operator (Operator::vmult, ref:include/operator.h:152-183): zero input, identity rows
+    //   EDGE_ROWS  zero input, but their ROWS are computed: the residual that is restricted (deal.II edge_out /
+    //              vmult_interface_down)
+    //   EDGE_IN    ordinary unconstrained DoFs: the edge matrix (vmult_interface_up, ref:include/operator.h:203-226)
+    enum EdgeMode
+    {
+      EDGE_OUT  = 0,
+      EDGE_ROWS = 1,
+      EDGE_IN   = 2
+    };
+
     template <int P, int MODE>
     void
-    apply_P(const T *src, const Epilogue<T> &epi, bool diag, double words)
+    apply_P(const T *src, const Epilogue<T> &epi, bool diag, double words, int edge_mode)
     {
       ApplyArgs<T, P> a;
+      const uint32_t  first_edge = tables->n_interior + tables->n_tail;
+      a.gather_limit  = first_edge + (edge_mode == EDGE_IN ? tables->n_edge : 0);
+      a.scatter_limit = first_edge + (edge_mode != EDGE_OUT ? tables->n_edge : 0);
+      const uint32_t tail_end = tables->n_tail + (edge_mode != EDGE_OUT ? tables->n_edge : 0);
       a.m          = mats<P>();
       a.src        = src;
       a.tail_acc   = tail_acc.p;
@@ -814,26 +830,26 @@ namespace mgamd
         }
       if (halo)
         exchange_add_raw(tail_acc.p); // complete the shared tail sums across ranks before the epilogue
-      launch_tail<MODE>(main, tail_done, tables->n_tail, true, epi, diag);
+      launch_tail<MODE>(main, tail_done, tail_end, true, epi, diag);
     }
 
     template <int MODE>
     void
-    apply(const T *src, const Epilogue<T> &epi, bool diag = false, double words = 0)
+    apply(const T *src, const Epilogue<T> &epi, bool diag = false, double words = 0, int edge_mode = EDGE_OUT)
     {
       switch (p)
         {
           case 1:
-            apply_P<1, MODE>(src, epi, diag, words);
+            apply_P<1, MODE>(src, epi, diag, words, edge_mode);
             break;
           case 2:
-            apply_P<2, MODE>(src, epi, diag, words);
+            apply_P<2, MODE>(src, epi, diag, words, edge_mode);
             break;
           case 3:
-            apply_P<3, MODE>(src, epi, diag, words);
+            apply_P<3, MODE>(src, epi, diag, words, edge_mode);
             break;
           case 4:
-            apply_P<4, MODE>(src, epi, diag, words);
+            apply_P<4, MODE>(src, epi, diag, words, edge_mode);
             break;
           default:
             throw std::runtime_error("degree not instantiated");
@@ -851,7 +867,39 @@ namespace mgamd
     residual_raw(T *t, const T *b, const T *x) // t = b - A x
     {
       Epilogue<T> e{t, x, nullptr, b, nullptr, T(0), T(0), T(0)};
-      apply<MODE_RESIDUAL>(x, e);
+      if (tables->n_edge == 0)
+        {
+          apply<MODE_RESIDUAL>(x, e);
+          return;
+        }
+      // local-smoothing level: the rows of the refinement-edge DoFs belong to the residual that is restricted,
+      // t_E = b_E - x_E - A_{E,I} x_I (identity row + coupling to the interior of the refined region)
+      apply<MODE_RESIDUAL>(x, e, false, 0, EDGE_ROWS);
+      const size_t first_edge = (size_t)tables->n_interior + tables->n_tail;
+      hipLaunchKernelGGL(vec_sadd_kernel<T>, grid_for(tables->n_edge), 256, 0, ctx->stream, t + first_edge, T(1), T(-1), x + first_edge,
+                         (size_t)tables->n_edge);
+    }
+    // dst = A^{edge DoFs unconstrained} (src restricted to the refinement-edge DoFs); tmp: scratch of n_dofs entries
+    // (Operator::vmult_interface_up, ref:include/operator.h:203-226)
+    void
+    interface_up_raw(T *dst, const T *src, T *tmp)
+    {
+      const size_t n = n_dofs(), first_edge = (size_t)tables->n_interior + tables->n_tail;
+      HIP_CHECK(hipMemsetAsync(tmp, 0, n * sizeof(T), ctx->stream));
+      if (tables->n_edge)
+        HIP_CHECK(hipMemcpyAsync(tmp + first_edge, src + first_edge, (size_t)tables->n_edge * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
+      Epilogue<T> e{dst, tmp, nullptr, nullptr, nullptr, T(0), T(0), T(0)};
+      apply<MODE_VMULT>(tmp, e, false, 0, EDGE_IN);
+    }
+    void
+    vmult_interface_up(mgamd_vec &dst, const mgamd_vec &src) override
+    {
+      if (dst.n != n_dofs() || src.n != n_dofs() || dst.data == src.data)
+        throw std::invalid_argument("vmult_interface_up: bad vectors");
+      DBuf<T> tmp;
+      tmp.alloc(n_dofs());
+      interface_up_raw(dst.as<T>(), src.as<T>(), tmp.p);
+      ctx->sync();
     }
     void
     cheb_raw(T *out, const T *x, const T *xold, const T *b, const T *dinv, double f1, double f2, int from_b = 0, double c0 = 0.0)
@@ -1599,6 +1647,51 @@ namespace mgamd
     hipGraphExec_t                   graph_exec = nullptr;
     const void                      *graph_z = nullptr, *graph_r = nullptr;
 
+    // Local smoothing (`HMG-local`): the levels are the refinement levels of the octree; the outer vectors live on the
+    // ACTIVE mesh and are copied level by level (copy_to_mg / copy_from_mg index pairs, transfer_tables.hpp)
+    struct LsCopy
+    {
+      DBuf<uint32_t> gidx, lidx;
+      uint32_t       n = 0;
+    };
+    std::vector<std::unique_ptr<LsCopy>> ls_copy;
+    size_t                               ls_n_global = 0;
+    void
+    setup_local_smoothing(const LevelTables &active) override
+    {
+      if (collapse_level || nested)
+        throw std::invalid_argument("local smoothing: not combinable with a nested coarse solver");
+      ls_copy.clear();
+      std::vector<uint32_t> g, l;
+      size_t                total = 0;
+      for (unsigned lv = 0; lv < nl; ++lv)
+        {
+          const LevelTables &T_l = *ops[lv]->tables;
+          if (!T_l.ls_level || T_l.tria->cells.empty())
+            throw std::invalid_argument("local smoothing: every level must be built with mgamd_dofs_create_level");
+          ls_copy_indices(active, T_l, (int)T_l.tria->cells[0].level, g, l);
+          auto c = std::make_unique<LsCopy>();
+          c->n   = (uint32_t)g.size();
+          if (c->n)
+            {
+              c->gidx.upload(g);
+              c->lidx.upload(l);
+            }
+          total += g.size();
+          ls_copy.push_back(std::move(c));
+        }
+      if (total != (size_t)active.n_interior + active.n_tail)
+        throw std::runtime_error("local smoothing: the levels do not cover every unconstrained DoF of the active mesh exactly once");
+      ls_n_global = active.n_dofs;
+      if (!defect[nl - 1]->p)
+        defect[nl - 1]->alloc(ops[nl - 1]->n_dofs());
+    }
+    size_t
+    n_outer() const
+    {
+      return ls_copy.empty() ? (size_t)ops[nl - 1]->n_dofs() : ls_n_global;
+    }
+
     uint64_t       coarse_iterations = 0; // inner CG iterations of the coarse solver, accumulated
     MultigridBase *nested   = nullptr; // coarse solver "gmg_vcycle"
     unsigned       n_cycles = 1;
@@ -1724,6 +1817,9 @@ namespace mgamd
       size_t max_n = 2048;
       if (const char *e = getenv("MGAMD_COLLAPSE_MAX_DOFS")) // 0 disables
         max_n = (size_t)atol(e);
+      for (unsigned l = 0; l < nl; ++l)
+        if (ops[l]->tables->ls_level)
+          return; // local smoothing: every level also receives its own part of the outer residual
       unsigned lc = 0;
       for (unsigned l = 1; l < nl; ++l)
         if (ops[l]->n_dofs() <= max_n && !ops[l]->comm)
@@ -1944,6 +2040,14 @@ namespace mgamd
       tr[l]->prolongate_raw(sview[l], sol[l - 1]);
       stage(4, false, l);
       stage(5, true, l); // edge_prolongation: no-op for global coarsening (ref:multigrid_throughput.cc:1126-1130)
+      if (ops[l]->tables->n_edge)
+        {
+          // local smoothing, Multigrid::set_edge_in_matrix (ref:multigrid_throughput.cc:1105,1130): the corrected solution on
+          // the refinement edge couples into the interior: defect_l -= A_l^{edge unconstrained} (x_l restricted to the edge)
+          const size_t n = ops[l]->n_dofs();
+          ops[l]->interface_up_raw(res[l]->p, sview[l], tview[l]);
+          hipLaunchKernelGGL(vec_sadd_kernel<T>, grid_for(n), 256, 0, ctx->stream, dptr[l], T(1), T(-1), res[l]->p, n);
+        }
       stage(5, false, l);
       stage(6, true, l);
       sol[l] = sm[l]->step_raw(sview[l], tview[l], dview[l]); // post-smoothing
@@ -1952,8 +2056,41 @@ namespace mgamd
 
     template <typename TO>
     void
+    vcycle_ls_raw(TO *z, const TO *r)
+    {
+      const unsigned L = nl - 1;
+      stage(7, true, L); // copy_to_mg: every level receives the residual entries of ITS active cells
+      if (nl > 1)
+        defect_slab.zero(ctx->stream);
+      HIP_CHECK(hipMemsetAsync(dptr[L], 0, (size_t)ops[L]->n_dofs() * sizeof(T), ctx->stream));
+      dview[L] = dptr[L];
+      sview[L] = S[L]->p;
+      tview[L] = Tb[L]->p;
+      for (unsigned l = 0; l < nl; ++l)
+        if (ls_copy[l]->n)
+          hipLaunchKernelGGL((indexed_copy_kernel<T, TO>), grid_for(ls_copy[l]->n), 256, 0, ctx->stream, dptr[l], ls_copy[l]->lidx.p, r,
+                             ls_copy[l]->gidx.p, ls_copy[l]->n);
+      stage(7, false, L);
+      level_v_step(L);
+      stage(8, true, L); // copy_from_mg
+      HIP_CHECK(hipMemsetAsync(z, 0, ls_n_global * sizeof(TO), ctx->stream));
+      for (unsigned l = 0; l < nl; ++l)
+        if (ls_copy[l]->n)
+          hipLaunchKernelGGL((indexed_copy_kernel<TO, T>), grid_for(ls_copy[l]->n), 256, 0, ctx->stream, z, ls_copy[l]->gidx.p,
+                             (const T *)sol[l], ls_copy[l]->lidx.p, ls_copy[l]->n);
+      stage(8, false, L);
+      HIP_CHECK(hipGetLastError());
+    }
+
+    template <typename TO>
+    void
     vcycle_raw(TO *z, const TO *r)
     {
+      if (!ls_copy.empty())
+        {
+          vcycle_ls_raw<TO>(z, r);
+          return;
+        }
       const size_t   n    = ops[nl - 1]->n_dofs();
       const unsigned L    = nl - 1;
       const bool     same = sizeof(TO) == sizeof(T) && nl > 1;
@@ -1998,7 +2135,7 @@ namespace mgamd
     void
     vcycle(mgamd_vec &z, const mgamd_vec &r) override
     {
-      const size_t n = ops[nl - 1]->n_dofs();
+      const size_t n = n_outer();
       if (z.n != n || r.n != n || z.type != r.type || z.data == r.data)
         throw std::invalid_argument("PreconditionMG::vmult: bad vectors");
       if (z.type == MGAMD_F64)

@@ -191,6 +191,8 @@ namespace mgamd
     vmult(mgamd_vec &dst, const mgamd_vec &src) = 0;
     virtual void
     compute_inverse_diagonal(mgamd_vec &d) = 0;
+    virtual void
+    vmult_interface_up(mgamd_vec &dst, const mgamd_vec &src) = 0; // local-smoothing levels: the edge matrix
     virtual size_t
     read_debug_stamps(unsigned long long *out, size_t max_count) = 0;
     void
@@ -233,6 +235,10 @@ namespace mgamd
     time_vcycles(mgamd_vec &z, const mgamd_vec &r, unsigned n, bool use_graph) = 0;
     virtual unsigned
     n_levels() const = 0;
+    // turn this hierarchy (levels built with mgamd_dofs_create_level) into a local-smoothing preconditioner of the problem on
+    // the active mesh `active`
+    virtual void
+    setup_local_smoothing(const LevelTables &active) = 0;
     // switch the tabulated (collapsed) coarse levels on/off at run time; returns the collapse level (0: none)
     virtual unsigned
     set_collapse(bool on) = 0;

@@ -150,6 +150,10 @@ namespace mgamd
               if (pf != pc)
                 throw std::runtime_error("transfer: refined cell in a p-transfer");
               kind = 1;
+              // local smoothing (MGTransferMatrixFree between refinement levels): the ACTIVE cells of the coarser level
+              // have no counterpart on the finer level and take no part in the transfer
+              if (coarse.ls_level && !tf.index.find(cell_key(cc.level + 1, 2 * cc.i, 2 * cc.j, 2 * cc.k)))
+                continue;
               // at the partition's root level the 8 children may belong to different ranks: keep the patch if any is ours
               bool any_local = false;
               for (int t = 0; t < 8; ++t)
@@ -219,4 +223,48 @@ namespace mgamd
         }
     }
   };
+} // namespace mgamd
+
+namespace mgamd
+{
+  // Local smoothing: copy_to_mg / copy_from_mg index pairs of one level (MGLevelGlobalTransfer with skip_interface_dofs,
+  // ref:multigrid_throughput.cc:1789-1791 MGTransferMatrixFree::build): the DoFs of the ACTIVE cells of refinement level
+  // `level`, except those on the level's refinement edge (they live on the coarser level) and the Dirichlet DoFs.
+  // global: tables of the active mesh (outer problem); lev: tables of the level mesh.
+  inline void
+  ls_copy_indices(const LevelTables &global, const LevelTables &lev, int level, std::vector<uint32_t> &gidx, std::vector<uint32_t> &lidx)
+  {
+    gidx.clear();
+    lidx.clear();
+    if (global.p != lev.p || !lev.ls_level)
+      throw std::invalid_argument("ls_copy_indices: need the active-mesh tables and a local-smoothing level of the same degree");
+    const Tria       &tg = *global.tria, &tl = *lev.tria;
+    const int         n  = global.p + 1;
+    std::vector<bool> seen(lev.n_dofs, false);
+    for (size_t gc = 0; gc < tg.cells.size(); ++gc)
+      {
+        const Cell &c = tg.cells[gc];
+        if ((int)c.level != level || !global.cell_is_local(gc))
+          continue;
+        const int32_t *lc = tl.index.find(cell_key(c));
+        if (!lc)
+          throw std::runtime_error("ls_copy_indices: active cell missing on its level mesh");
+        for (int z = 0; z < n; ++z)
+          for (int y = 0; y < n; ++y)
+            for (int x = 0; x < n; ++x)
+              {
+                const int      a[3] = {x, y, z};
+                const uint32_t li   = lev.cell_node_index((size_t)*lc, a);
+                if (li == INVALID_DOF || li >= lev.first_constrained() || seen[li])
+                  continue; // Dirichlet, refinement edge, or already listed
+                bool           constrained = false;
+                const uint32_t gi          = global.cell_node_index(gc, a, &constrained);
+                if (constrained || gi == INVALID_DOF || gi >= global.first_constrained())
+                  throw std::runtime_error("ls_copy_indices: a level-interior DoF of an active cell is constrained on the active mesh");
+                seen[li] = true;
+                gidx.push_back(gi);
+                lidx.push_back(li);
+              }
+      }
+  }
 } // namespace mgamd

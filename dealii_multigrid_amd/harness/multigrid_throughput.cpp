@@ -5,8 +5,8 @@
 //
 //   ./multigrid_throughput input_0000.json [input_0001.json ...]
 //
-// Implemented `Type`s: HMG-global, PMG, HPMG (global coarsening).  HMG-local/HPMG-local/AMG/AMGPETSc raise
-// "not implemented" exactly like the reference's AssertThrow(false, ExcNotImplemented()) for unknown strings.
+// Implemented `Type`s: HMG-global, PMG, HPMG (global coarsening) and HMG-local (local smoothing).  HPMG-local/AMG/AMGPETSc
+// raise "not implemented" exactly like the reference's AssertThrow(false, ExcNotImplemented()) for unknown strings.
 #include "../csrc/mgamd.hpp"
 
 #include <algorithm>
@@ -303,8 +303,16 @@ run(const Context &ctx, const RunParameters &params, ConvergenceTable &table)
           degrees.push_back(pseq[i]);
         }
     }
+  else if (params.type == "HMG-local")
+    {
+      // solve_with_local_smoothing (ref:multigrid_throughput.cc:1670-1873): the levels are the refinement levels of the mesh
+      for (unsigned l = 0; l < tria->n_global_levels(); ++l)
+        triangulations.push_back(tria->level_mesh(l));
+      degrees.assign(triangulations.size(), params.fe_degree_fine);
+    }
   else
     throw std::runtime_error("Type '" + params.type + "': not implemented");
+  const bool local_smoothing = params.type == "HMG-local";
 
   const unsigned                  n_levels = degrees.size();
   std::vector<DoFHandler>         dof_handlers;
@@ -312,7 +320,11 @@ run(const Context &ctx, const RunParameters &params, ConvergenceTable &table)
   std::vector<MGTwoLevelTransfer> transfers(n_levels);
   std::vector<PreconditionChebyshev> smoothers(n_levels);
   for (unsigned l = 0; l < n_levels; ++l)
-    dof_handlers.emplace_back(triangulations[l], degrees[l]);
+    dof_handlers.emplace_back(triangulations[l], degrees[l], -1, local_smoothing);
+  std::unique_ptr<DoFHandler> active_dof_handler;
+  if (local_smoothing)
+    active_dof_handler = std::make_unique<DoFHandler>(tria, params.fe_degree_fine);
+  const DoFHandler &fine_dof_handler = local_smoothing ? *active_dof_handler : dof_handlers.back();
   for (unsigned l = 0; l < n_levels; ++l)
     operators[l].reinit(ctx, dof_handlers[l], level_number_type);
   for (unsigned l = 1; l < n_levels; ++l)
@@ -356,14 +368,15 @@ run(const Context &ctx, const RunParameters &params, ConvergenceTable &table)
                 << "-DoF coarse level: Trilinos/PETSc are not available, using " << params.mg_data.coarse_solver.n_cycles
                 << " V-cycle(s) of the geometric multigrid on that level (gmg_vcycle)" << std::endl;
     }
-  PreconditionMG preconditioner(ctx, operators, transfers, smoothers, coarse, coarse_mg.get(), params.mg_data.coarse_solver.n_cycles);
+  PreconditionMG preconditioner(ctx, operators, transfers, smoothers, coarse, coarse_mg.get(), params.mg_data.coarse_solver.n_cycles,
+                                active_dof_handler.get());
 
   // fine (outer, double) operator, right-hand side (ref:multigrid_throughput.cc:2262-2324)
   Operator op;
-  if (level_number_type == MGAMD_F64)
+  if (level_number_type == MGAMD_F64 && !local_smoothing)
     op = operators.back();
   else
-    op.reinit(ctx, dof_handlers.back(), MGAMD_F64);
+    op.reinit(ctx, fine_dof_handler, MGAMD_F64);
   Vector solution, rhs;
   op.initialize_dof_vector(solution);
   op.initialize_dof_vector(rhs);
@@ -376,7 +389,7 @@ run(const Context &ctx, const RunParameters &params, ConvergenceTable &table)
   table.add_value("degree", params.fe_degree_fine);
   table.add_value("n_ref_global", params.n_ref_global);
   table.add_value("n_ref_local", params.n_ref_local);
-  table.add_value("n_dofs", dof_handlers.back().n_dofs());
+  table.add_value("n_dofs", fine_dof_handler.n_dofs());
   table.add_value("sub_comm_size", 1);
 
   if (params.verbose)

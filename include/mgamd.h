@@ -81,6 +81,9 @@ typedef struct
   uint32_t n_tail_owned, n_dirichlet_owned, n_hanging_owned;
   uint32_t n_peers;       /* ranks this rank exchanges partial sums with on this level               */
   uint32_t n_halo_send;   /* tail entries sent (= received) per exchange                              */
+  /* local-smoothing levels (mgamd_dofs_create_level): refinement-edge DoFs, numbered between the tail and the Dirichlet
+   * DoFs: [ I | T | E | D | H ] */
+  uint32_t n_edge;
 } mgamd_dofs_info_t;
 
 /* DoFHandler::distribute_dofs(FE_Q(degree)) + zero Dirichlet on boundary id 0 + hanging-node
@@ -109,6 +112,16 @@ int mgamd_dofs_rhs_constant(const mgamd_dofs *d, double *out);
  * (ref:include/operator.h:362-447); and AffineConstraints::distribute on a host vector of n_dofs values */
 int mgamd_dofs_rhs(const mgamd_dofs *d, int kind, double *out);
 int mgamd_dofs_distribute(const mgamd_dofs *d, int kind, double *x);
+
+/* Local smoothing (`HMG-local`, ref:multigrid_throughput.cc:1670-1873): level `level` of the refinement hierarchy = ALL
+ * cells of that refinement level, active or not (DoFHandler::distribute_mg_dofs); its DoFs + zero Dirichlet boundary +
+ * refinement-edge set (MGConstrainedDoFs / MGTools::extract_inner_interface_dofs, ref:include/operator.h:49-70,539-556);
+ * and the copy_to_mg / copy_from_mg index pairs of that level (MGLevelGlobalTransfer, interface DoFs skipped): call with
+ * NULL arrays for the count. */
+int mgamd_tria_level_mesh(const mgamd_tria *fine, unsigned level, mgamd_tria **out);
+int mgamd_dofs_create_level(const mgamd_tria *level_mesh, int degree, int max_brick, mgamd_dofs **out);
+int mgamd_ls_copy_indices(const mgamd_dofs *active_mesh_dofs, const mgamd_dofs *level_dofs, unsigned level, uint64_t *count,
+                          uint32_t *global_idx, uint32_t *level_idx);
 
 /* Domain decomposition (the reference partitions with p4est + RepartitioningPolicyTools,
  * ref:multigrid_throughput.cc:2066-2175).  trias: the level meshes, coarsest first.  A root level is chosen; its leaves are
@@ -241,6 +254,17 @@ int mgamd_mg_create_nested(mgamd_ctx *ctx, unsigned n_levels, mgamd_level_op *co
                            mgamd_cheb *const *smoothers, const char *coarse_solver, mgamd_mg *coarse_mg, unsigned n_cycles,
                            mgamd_mg **out);
 int mgamd_mg_coarse_solver_used(const mgamd_mg *mg, char name[32]);
+/* Local smoothing (`HMG-local`: solve_with_local_smoothing, ref:multigrid_throughput.cc:1670-1873).  levels[l] = Operator on
+ * refinement level l (mgamd_dofs_create_level: edge-constrained level operator, ref:include/operator.h:49-120,152-183),
+ * transfers = MGTransferMatrixFree between the refinement levels, Multigrid with the interface (edge) matrices
+ * (ref:multigrid_throughput.cc:1081-1130), PreconditionMG::vmult on vectors of the ACTIVE mesh `active_mesh_dofs`
+ * (copy_to_mg / copy_from_mg).  Stage 5 of the stage callback / timing is the edge prolongation. */
+int mgamd_mg_create_local_smoothing(mgamd_ctx *ctx, unsigned n_levels, mgamd_level_op *const *levels, mgamd_transfer2 *const *transfers,
+                                    mgamd_cheb *const *smoothers, const mgamd_dofs *active_mesh_dofs, const char *coarse_solver,
+                                    mgamd_mg **out);
+/* Operator::vmult_interface_up (ref:include/operator.h:203-226): dst = A with the refinement-edge DoFs unconstrained, applied
+ * to src restricted to those DoFs (MatrixFreeOperators::MGInterfaceOperator::Tvmult) */
+int mgamd_level_op_vmult_interface_up(mgamd_level_op *op, mgamd_vec *dst, const mgamd_vec *src);
 /* Levels up to 2048 DoFs (MGAMD_COLLAPSE_MAX_DOFS) with a direct coarse solver are applied as ONE tabulated dense matrix
  * (the zero-start V-cycle below a level is a linear map of its defect; result-equivalent).  This switches the
  * tabulated path off/on at run time (bench.py reports the cycle time both ways); *collapse_level = the level it replaces

@@ -473,8 +473,10 @@ def gaussian_rhs(x, y, z, width=0.1, centre=(-0.5, -0.5, -0.5)):
 # ----------------------------------------------------------------------------
 # Two-level transfer (deal.II MGTwoLevelTransfer)
 # ----------------------------------------------------------------------------
-def build_transfer(fine: Level, coarse: Level) -> sp.csr_matrix:
-    """P (n_f x n_c): x_f += P x_c is prolongate_and_add, d_c += P^T r_f is restrict_and_add."""
+def build_transfer(fine: Level, coarse: Level, allow_uncovered=False) -> sp.csr_matrix:
+    """P (n_f x n_c): x_f += P x_c is prolongate_and_add, d_c += P^T r_f is restrict_and_add.
+    allow_uncovered: coarse cells without a counterpart on the fine level are skipped (local smoothing: the active cells
+    of the coarser level)."""
     pf, pc = fine.p, coarse.p
     nf1, nc1 = pf + 1, pc + 1
     fcell_index = {c: i for i, c in enumerate(fine.cells)}
@@ -487,6 +489,8 @@ def build_transfer(fine: Level, coarse: Level) -> sp.csr_matrix:
             fcells = [cc]
         else:
             fcells = _children(cc)
+            if allow_uncovered and not any(f in fine.leaves for f in fcells):
+                continue
             assert all(f in fine.leaves for f in fcells)
         pts = {}  # fine dof -> reference point in coarse cell
         for fc in fcells:

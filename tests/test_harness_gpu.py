@@ -100,7 +100,28 @@ def test_amg_on_a_large_coarse_level_runs_the_geometric_stand_in(oracle, tmp_pat
     assert int(rows[0]["n_iterations"]) == oracle_iterations(oracle, "annulus", 6, 2, "HPMG")
 
 
-@pytest.mark.parametrize("key,value,message", [("Type", "HMG-local", "not implemented"), ("Type", "AMG", "not implemented"),
+def test_local_smoothing_inputs(tmp_path):
+    """input_0000.json / input_0002.json of scripts/small-scaling.py are the `HMG-local` siblings of the golden inputs: same
+    mesh and DoF counts, n_levels = refinement levels, iteration counts of the local-smoothing oracle (float levels: +-1),
+    and a non-zero edge-prolongation column (ref:multigrid_throughput.cc:1189-1190,1391)."""
+    import ls_oracle
+
+    files = []
+    for name, p in (("input_0001.json", 1), ("input_0003.json", 4)):
+        cfg = dict(json.load(open(os.path.join(GOLDEN, name))), Type="HMG-local")
+        files.append(str(tmp_path / f"ls{p}.json"))
+        json.dump(cfg, open(files[-1], "w"))
+    rc, out, err = run_harness(*files)
+    assert rc == 0, err
+    header, rows = final_table(out)
+    assert header[:len(REFERENCE_COLUMNS)] == REFERENCE_COLUMNS
+    for r, p, n in zip(rows, (1, 4), (223, 9295)):
+        assert (int(r["n_cells"]), int(r["n_dofs"]), int(r["n_levels"])) == (120, n, 4)
+        assert abs(int(r["n_iterations"]) - ls_oracle.LocalSmoothing("quadrant", 3, p).solve(1e-4)[1]) <= 1
+        assert float(r["time_edge_pro"]) > 0 and r["coarse_solver"] == "direct"
+
+
+@pytest.mark.parametrize("key,value,message", [("Type", "HPMG-local", "not implemented"), ("Type", "AMG", "not implemented"),
                                                ("GeometryType", "torus", "not implemented"), ("MGNumberType", "half", "not implemented"),
                                                ("CoarseGridSolverType", "lu", "not implemented")])
 def test_error_behaviour(tmp_path, key, value, message):

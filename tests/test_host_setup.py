@@ -235,3 +235,28 @@ def test_pipeline_stages_of_the_tail(mgamd, oracle, geo, L, p, chunks, monkeypat
     # same operator as without the staging (numbering-independent check through the oracle)
     lv = oracle_level(oracle, d, geo, L, p)
     assert d.n_dofs == lv.n and np.abs(d.rhs_constant() - lv.rhs_constant).max() < 1e-15
+
+
+@pytest.mark.parametrize("geo,L,p", [("quadrant", 3, 1), ("quadrant", 4, 2), ("annulus", 5, 1), ("quadrant", 3, 4)])
+def test_local_smoothing_level_tables(mgamd, geo, L, p):
+    """HMG-local host tables against the textbook oracle: level meshes (all cells of a refinement level), DoF counts,
+    refinement-edge sets (numbered [I | T | E | D]), copy_to_mg / copy_from_mg index pairs -- through the DoF keys"""
+    import ls_oracle
+
+    fine = mgamd.Triangulation(geo, L)
+    act = mgamd.DoFs(fine, p, 0)
+    s = ls_oracle.LocalSmoothing(geo, L, p)
+    act_keys = [tuple(int(v) for v in k) for k in act.keys()]
+    for l in range(fine.n_levels):
+        d = mgamd.DoFs(fine.level_mesh(l), p, 0, local_smoothing_level=True)
+        Lv = s.levels[l]
+        assert d.n_dofs == Lv.n and d.info.n_edge == Lv.edge.sum() and d.info.n_hanging == 0
+        keys = [tuple(int(v) for v in k) for k in d.keys()]
+        fe = d.info.n_interior + d.info.n_tail
+        assert {keys[i] for i in range(fe, fe + d.info.n_edge)} == {Lv.keys[i] for i in np.nonzero(Lv.edge)[0]}
+        assert {keys[i] for i in range(fe + d.info.n_edge, d.n_dofs)} == {Lv.keys[i] for i in np.nonzero(Lv.dirichlet)[0]}
+        g, li = mgamd.ls_copy_indices(act, d, l)
+        og, ol = s.copy[l]
+        assert {(act_keys[a], keys[b]) for a, b in zip(g, li)} == {(s.G.keys[a], Lv.keys[b]) for a, b in zip(og, ol)}
+    with pytest.raises(mgamd.MgamdError, match="level"):
+        fine.level_mesh(fine.n_levels)
