@@ -147,6 +147,12 @@ class Partition:
         _chk(_lib.mgamd_partition_info(self._h, C.byref(rl), None))
         self.root_level = rl.value
 
+    def statistics(self):
+        """MGTools::print_multigrid_statistics (ref:include/mg_tools.h:267-512) for this partition"""
+        st = (C.c_double * 5)()
+        _chk(_lib.mgamd_partition_statistics(self._h, st))
+        return dict(zip(("workload_eff", "workload_path_max", "vertical_eff", "horizontal_eff", "mem_total"), st))
+
     def owner(self, level: int):
         o = np.zeros(self.trias[level].n_cells, np.uint16)
         _chk(_lib.mgamd_partition_get_owner(self._h, level, _ptr(o)))

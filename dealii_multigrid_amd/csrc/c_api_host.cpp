@@ -366,6 +366,24 @@ mgamd_partition_info(const mgamd_partition *p, unsigned *root_level, unsigned *n
 }
 
 int
+mgamd_partition_statistics(const mgamd_partition *p, double stats[5])
+{
+  MGAMD_TRY
+  if (!p || !stats)
+    throw std::invalid_argument("null argument");
+  std::vector<const Tria *> trias;
+  for (const auto &t : p->trias)
+    trias.push_back(t.get());
+  const PartitionStatistics st = partition_statistics(trias, p->part);
+  stats[0] = st.workload_eff;
+  stats[1] = st.workload_path_max;
+  stats[2] = st.vertical_eff;
+  stats[3] = st.horizontal_eff;
+  stats[4] = st.mem_total;
+  MGAMD_CATCH
+}
+
+int
 mgamd_partition_get_owner(const mgamd_partition *p, unsigned level, uint16_t *owner)
 {
   MGAMD_TRY

@@ -106,6 +106,28 @@ namespace mgamd
     return {seq.rbegin(), seq.rend()};
   }
 
+  // MGTools::print_multigrid_statistics(triangulations) (ref:include/mg_tools.h:267-512, ref:multigrid_throughput.cc:1657-1665):
+  // {workload_eff, workload_path_max, vertical_eff, horizontal_eff, mem_total} of the n_ranks-way partition of the level
+  // meshes (coarse -> fine)
+  inline std::vector<std::pair<std::string, double>>
+  print_multigrid_statistics(const std::vector<std::shared_ptr<const Triangulation>> &triangulations, unsigned n_ranks = 1)
+  {
+    std::vector<const mgamd_tria *> t;
+    for (const auto &x : triangulations)
+      t.push_back(x->get());
+    mgamd_partition *p = nullptr;
+    check(mgamd_partition_create_ex(t.data(), (unsigned)t.size(), n_ranks, 2.0, 0, &p));
+    double     st[5];
+    const int  rc = mgamd_partition_statistics(p, st);
+    mgamd_partition_destroy(p);
+    check(rc);
+    static const char *names[5] = {"workload_eff", "workload_path_max", "vertical_eff", "horizontal_eff", "mem_total"};
+    std::vector<std::pair<std::string, double>> out;
+    for (int i = 0; i < 5; ++i)
+      out.emplace_back(names[i], st[i]);
+    return out;
+  }
+
   // ...::create_polynomial_coarsening_sequence(degree, bisect) (ref:multigrid_throughput.cc:1506-1510)
   inline std::vector<unsigned>
   create_polynomial_coarsening_sequence(unsigned degree)

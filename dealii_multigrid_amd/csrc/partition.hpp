@@ -17,6 +17,7 @@
 #include "level_tables.hpp"
 
 #include <map>
+#include <set>
 
 namespace mgamd
 {
@@ -98,6 +99,122 @@ namespace mgamd
           }
       }
     return P;
+  }
+
+  // Partition-quality statistics of the level hierarchy, as the reference prints them in verbose mode
+  // (MGTools::print_multigrid_statistics for a vector of triangulations, ref:include/mg_tools.h:267-512,
+  // ref:multigrid_throughput.cc:1657-1665), evaluated for THIS partition (every rank knows all owners, so no communication):
+  //   workload_eff       = [sum_l sum_r n_l,r / n_ranks] / [sum_l max_r n_l,r]       (mg_tools.h:9-38,285-286)
+  //   workload_path_max  = sum_l max_r n_l,r                                          (mg_tools.h:306-309)
+  //   vertical_eff       = children on the parent's rank / all children of refined cells  (mg_tools.h:140-204,372-373)
+  //   horizontal_eff     = (local + ghost / 2) / (local + ghost), ghost = foreign cells in the 26-neighbourhood of owned
+  //                        cells (mg_tools.h:228-247,437-439)
+  //   mem_total          = bytes of the level meshes held by all ranks                (mg_tools.h:249-258,487-488)
+  // n_l,r = cells of level l owned by rank r; a replicated level counts fully on every rank (every rank does that work).
+  struct PartitionStatistics
+  {
+    double workload_eff = 1, workload_path_max = 0, vertical_eff = 1, horizontal_eff = 1, mem_total = 0;
+  };
+
+  inline PartitionStatistics
+  partition_statistics(const std::vector<const Tria *> &trias, const Partition &P)
+  {
+    PartitionStatistics st;
+    const int           nl = (int)trias.size(), nr = P.n_ranks;
+    double              sum_all = 0, path = 0, v_local = 0, v_remote = 0, h_local = 0, h_remote = 0;
+    for (int l = 0; l < nl; ++l)
+      {
+        const Tria         &t = *trias[l];
+        std::vector<double> n(nr, 0.0);
+        if (P.replicated(l) || nr == 1)
+          for (int r = 0; r < nr; ++r)
+            n[r] = (double)t.n_cells();
+        else
+          for (uint16_t o : P.level_owner(l))
+            n[o] += 1.0;
+        double mx = 0;
+        for (double v : n)
+          {
+            sum_all += v;
+            mx = std::max(mx, v);
+          }
+        path += mx;
+        st.mem_total += (double)nr * ((double)t.cells.size() * (sizeof(Cell) + sizeof(uint16_t) + 16.0));
+        const bool dist = !(P.replicated(l) || nr == 1);
+        // horizontal: ghost cells of every rank
+        for (int r = 0; r < nr; ++r)
+          h_local += n[r];
+        if (dist)
+          {
+            const auto                 &own = P.level_owner(l);
+            for (size_t c = 0; c < t.n_cells(); ++c)
+              {
+                // ranks (other than the owner) that see cell c as a ghost: owners of its 26 neighbours
+                const Cell &cc = t.cells[c];
+                uint64_t    ranks = 0;
+                for (int dz = -1; dz <= 1; ++dz)
+                  for (int dy = -1; dy <= 1; ++dy)
+                    for (int dx = -1; dx <= 1; ++dx)
+                      {
+                        if (!dx && !dy && !dz)
+                          continue;
+                        const int nb = t.find_leaf(cc.level, (int64_t)cc.i + dx, (int64_t)cc.j + dy, (int64_t)cc.k + dz);
+                        if (nb >= 0)
+                          ranks |= 1ull << own[nb];
+                        else
+                          for (int q = 0; q < 8; ++q)
+                            {
+                              // the neighbour position is refined (or outside): its children on the side facing c touch c
+                              const int qb[3] = {q & 1, (q >> 1) & 1, q >> 2}, dd[3] = {dx, dy, dz};
+                              bool      faces = true;
+                              for (int d = 0; d < 3; ++d)
+                                faces &= dd[d] == 0 || qb[d] == (dd[d] < 0 ? 1 : 0);
+                              if (!faces)
+                                continue;
+                              const int f = t.find_leaf(cc.level + 1, 2 * ((int64_t)cc.i + dx) + qb[0], 2 * ((int64_t)cc.j + dy) + qb[1],
+                                                        2 * ((int64_t)cc.k + dz) + qb[2]);
+                              if (f >= 0)
+                                ranks |= 1ull << own[f];
+                            }
+                      }
+                ranks &= ~(1ull << own[c]);
+                h_remote += (double)__builtin_popcountll(ranks);
+              }
+          }
+        // vertical: children of the refined cells of level l on level l + 1
+        if (l + 1 < nl)
+          {
+            const Tria &tf    = *trias[l + 1];
+            const bool  distf = !(P.replicated(l + 1) || nr == 1);
+            for (size_t c = 0; c < t.n_cells(); ++c)
+              {
+                const Cell &cc = t.cells[c];
+                if (tf.index.find(cell_key(cc)))
+                  continue; // not refined between the two levels
+                for (int q = 0; q < 8; ++q)
+                  {
+                    const int32_t *f = tf.index.find(cell_key(cc.level + 1, 2 * cc.i + (q & 1), 2 * cc.j + ((q >> 1) & 1), 2 * cc.k + (q >> 2)));
+                    if (!f)
+                      continue;
+                    if (!dist && !distf)
+                      v_local += nr; // replicated pair: local on every rank
+                    else if (!dist)
+                      { // replicated parent, distributed child: local for the child's owner, remote for nobody
+                        v_local += 1;
+                      }
+                    else if (P.level_owner(l)[c] == P.level_owner(l + 1)[*f])
+                      v_local += 1;
+                    else
+                      v_remote += 1;
+                  }
+              }
+          }
+      }
+    st.workload_path_max = path;
+    st.workload_eff      = path > 0 ? (sum_all / nr) / path : 1.0;
+    st.vertical_eff      = (v_local + v_remote) > 0 ? v_local / (v_local + v_remote) : 1.0;
+    st.horizontal_eff    = (h_local + h_remote) > 0 ? (h_local + 0.5 * h_remote) / (h_local + h_remote) : 1.0;
+    return st;
   }
 
   // Keys referenced by the cells of `rank` that have a leaf of another rank in their 26-neighbourhood, sorted by key.

@@ -461,6 +461,19 @@ run(const Context &ctx, const RunParameters &params, ConvergenceTable &table)
   table.add_value("time_to_mg", t_to_mg, true);
   table.add_value("time_to_global", t_to_global, true);
   t_v += t_to_mg + t_to_global;
+  if (params.verbose)
+    {
+      // partition statistics of the level meshes (ref:multigrid_throughput.cc:1657-1665, ref:include/mg_tools.h:267-512); the
+      // p-levels of PMG/HPMG repeat the finest mesh: every distinct mesh once, coarse -> fine
+      std::vector<std::shared_ptr<const Triangulation>> meshes;
+      for (const auto &t : triangulations)
+        if (meshes.empty() || meshes.back().get() != t.get())
+          meshes.push_back(t);
+      if (local_smoothing || meshes.size() == 1)
+        meshes = create_geometric_coarsening_sequence(tria); // one mesh: its coarsening sequence (the level hierarchy)
+      for (const auto &stat : print_multigrid_statistics(meshes, 1))
+        table.add_value(stat.first, stat.second, true);
+    }
   // this project's additions (after the reference's columns): DoF/s per V-cycle = n_dofs / (sum of the nine stage columns)
   //  and the coarse solver that actually ran
   table.add_value("dofs_per_s_per_vcycle", (double)rhs.size() / t_v, true);

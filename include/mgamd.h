@@ -134,6 +134,10 @@ int mgamd_partition_create(const mgamd_tria *const *trias, unsigned n_levels, un
 int mgamd_partition_create_ex(const mgamd_tria *const *trias, unsigned n_levels, unsigned n_ranks, double hanging_weight,
                               uint64_t min_root_cells, mgamd_partition **out);
 int mgamd_partition_destroy(mgamd_partition *p);
+/* MGTools::print_multigrid_statistics for this partition (ref:include/mg_tools.h:267-512; verbose-mode table columns
+ * workload_eff, workload_path_max, vertical_eff, horizontal_eff, mem_total: ref:multigrid_throughput.cc:1657-1665), in that
+ * order in stats[5]; definitions in csrc/partition.hpp */
+int mgamd_partition_statistics(const mgamd_partition *p, double stats[5]);
 int mgamd_partition_info(const mgamd_partition *p, unsigned *root_level, unsigned *n_ranks);
 /* owner rank of every cell of a distributed level (level >= root_level) */
 int mgamd_partition_get_owner(const mgamd_partition *p, unsigned level, uint16_t *owner);

@@ -48,7 +48,9 @@ def test_reference_generated_inputs(oracle):
     assert rc == 0, err
     header, rows = final_table(out)
     assert header[:len(REFERENCE_COLUMNS)] == REFERENCE_COLUMNS
-    assert header[len(REFERENCE_COLUMNS):] == ["dofs_per_s_per_vcycle", "coarse_solver"]
+    # Verbosity true: the partition statistics of ref:include/mg_tools.h:316-317,377,443,491, then this project's additions
+    assert header[len(REFERENCE_COLUMNS):] == ["workload_eff", "workload_path_max", "vertical_eff", "horizontal_eff", "mem_total",
+                                               "dofs_per_s_per_vcycle", "coarse_solver"]
     assert len(rows) == 2
     r1, r4 = rows
     assert (int(r1["dim"]), int(r1["n_cells"]), int(r1["n_cells_hn"]), int(r1["n_dofs"]), int(r1["n_levels"])) == (3, 120, 37, 223, 4)
@@ -65,6 +67,8 @@ def test_reference_generated_inputs(oracle):
         assert float(r["time_edge_pro"]) < 0.2 * stages  # no edge matrices in global coarsening
         assert float(r["dofs_per_s_per_vcycle"]) == pytest.approx(n / stages, rel=2e-3)
         assert r["coarse_solver"] == "direct"
+    assert float(r1["workload_eff"]) == 1.0 and float(r1["vertical_eff"]) == 1.0 and float(r1["horizontal_eff"]) == 1.0  # one rank
+    assert float(r1["workload_path_max"]) == 1 + 8 + 15 + 120 and float(r1["mem_total"]) > 0
     assert "cells" in out and "dofs" in out  # Verbosity: the per-level table (ref:multigrid_throughput.cc:1644-1655)
 
 

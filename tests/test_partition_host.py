@@ -95,3 +95,69 @@ def test_min_root_cells_keeps_small_levels_replicated(mgamd):
     assert mgamd.Partition(trias, 4, 2.0, min_root_cells=n_fine + 1).root_level == len(trias) - 1  # never beyond the finest
     o = part.owner(len(trias) - 1)
     assert set(np.unique(o)) == {0, 1, 2, 3}
+
+
+def test_partition_statistics_match_a_python_restatement(mgamd):
+    """MGTools::print_multigrid_statistics (ref:include/mg_tools.h:9-38,140-247,267-512) for the Morton-chunk partition:
+    workload efficiency / longest path, vertical efficiency (children on the parent's rank) and horizontal efficiency
+    (ghost cells = foreign vertex neighbours), restated here cell by cell in Python."""
+    fine = mgamd.Triangulation("quadrant", 5)
+    trias = mgamd.create_geometric_coarsening_sequence(fine)
+    n_ranks = 4
+    part = mgamd.Partition(trias, n_ranks, 2.0, 0)
+    st = part.statistics()
+    root = part.root_level
+    cells, owners = [], []
+    for l, t in enumerate(trias):
+        lev, i, j, k, _ = t.cells()
+        cells.append(list(zip(lev.tolist(), i.tolist(), j.tolist(), k.tolist())))
+        owners.append(part.owner(l).tolist() if l >= root else None)
+    # workload
+    per_level = []
+    for l in range(len(trias)):
+        n = [len(cells[l])] * n_ranks if owners[l] is None else [owners[l].count(r) for r in range(n_ranks)]
+        per_level.append(n)
+    path = sum(max(n) for n in per_level)
+    assert st["workload_path_max"] == path
+    assert st["workload_eff"] == pytest.approx(sum(sum(n) for n in per_level) / n_ranks / path, rel=1e-12)
+    # vertical
+    loc = rem = 0
+    for l in range(len(trias) - 1):
+        fine_idx = {c: t for t, c in enumerate(cells[l + 1])}
+        for ci, (lv, i, j, k) in enumerate(cells[l]):
+            if (lv, i, j, k) in fine_idx:
+                continue
+            for q in range(8):
+                f = fine_idx.get((lv + 1, 2 * i + (q & 1), 2 * j + ((q >> 1) & 1), 2 * k + (q >> 2)))
+                if f is None:
+                    continue
+                if owners[l] is None and owners[l + 1] is None:
+                    loc += n_ranks
+                elif owners[l] is None or owners[l][ci] == owners[l + 1][f]:
+                    loc += 1
+                else:
+                    rem += 1
+    assert st["vertical_eff"] == pytest.approx(loc / (loc + rem), rel=1e-12) and st["vertical_eff"] == 1.0  # children inherit the rank
+    # horizontal: ghosts by geometric adjacency (closed cells intersect)
+    h_loc = sum(sum(n) for n in per_level)
+    h_rem = 0
+    for l in range(root, len(trias)):
+        L = max(c[0] for c in cells[l])
+        boxes = [((i << (L - lv)), (j << (L - lv)), (k << (L - lv)), 1 << (L - lv)) for lv, i, j, k in cells[l]]
+        import itertools
+        grid = {}
+        for t, (x, y, z, s) in enumerate(boxes):
+            for gx, gy, gz in itertools.product(range(x, x + s), range(y, y + s), range(z, z + s)):
+                grid[(gx, gy, gz)] = t
+        for t, (x, y, z, s) in enumerate(boxes):
+            ranks = set()
+            for gx, gy, gz in itertools.product(range(x - 1, x + s + 1), range(y - 1, y + s + 1), range(z - 1, z + s + 1)):
+                nb = grid.get((gx, gy, gz))
+                if nb is not None and nb != t:
+                    ranks.add(owners[l][nb])
+            ranks.discard(owners[l][t])
+            h_rem += len(ranks)
+    assert st["horizontal_eff"] == pytest.approx((h_loc + 0.5 * h_rem) / (h_loc + h_rem), rel=1e-12)
+    assert 0.5 < st["horizontal_eff"] < 1.0 and st["mem_total"] > 0
+    one = mgamd.Partition(trias, 1, 2.0, 0).statistics()
+    assert one["workload_eff"] == 1.0 and one["vertical_eff"] == 1.0 and one["horizontal_eff"] == 1.0
