@@ -49,6 +49,15 @@ namespace mgamd
     double               Me[NH * NH], Mo[NO * NO], Ke[NH * NH], Ko[NO * NO];
   };
 
+  // Bricks that may carry whole-face / whole-edge hanging-node constraints (see lattice_apply_body): families (B = 2) share
+  // the kernel of the 2^3 bricks; larger constrained bricks (p = 1 only, LevelTables::build) are a slot group of their own
+  // with their own kernel instantiation (CONSTR), so that the plain bricks keep the lean kernel.
+  constexpr bool
+  brick_may_be_constrained(int B, bool constr)
+  {
+    return B == 2 || (constr && B > 2);
+  }
+
   template <int P, int B>
   struct Geo
   {
@@ -75,7 +84,7 @@ namespace mgamd
     const double   *h;
     const uint16_t *shell_pos;
     uint32_t        n_slots;
-    const uint32_t *fmask; // B == 2: family masks of constrained bricks (level_tables.hpp), nullptr if the group has none
+    const uint32_t *fmask; // bricks: masks of the constrained ones (level_tables.hpp), nullptr if the group has none
   };
 
   enum ApplyMode
@@ -572,72 +581,100 @@ namespace mgamd
       }
   }
 
-  // Constrained 2^3 bricks (families with hanging faces/edges, level_tables.hpp): the parent's face/edge DoFs sit on
-  // the entity (parent coordinate c at lattice coordinate c, c = P at 2P); this embeds them in place along every lattice line that lies in a hanging face (or is
-  // a hanging edge), direction by direction (x, y, z), with E = [I0; I1]; transpose = the reverse.  One thread per
-  // line (sl, u, v) as in the sweeps.  Ends with a barrier.
-  template <typename T, int P>
+  // Constrained bricks (level_tables.hpp): bricks next to coarser cells whose hanging entities are whole faces / whole edges
+  // of the brick (B = 2: a family, the 8 children of one cell).  The parents' face/edge DoFs sit ON the entity: along a
+  // lattice line the parent DoF k P + c of parent cell k is at lattice coordinate 2 k P + c (c < P; c = P: the next parent
+  // cell's first position, B P at the end); this embeds them in place along every lattice line that lies in a hanging face
+  // (or is a hanging edge), direction by direction (x, y, z), with E = [I0; I1] per parent cell; transpose = the reverse.
+  // One thread per line (sl, u, v) as in the sweeps, in rounds of BLOCK lines.  Ends with a barrier.
+  template <typename T, int P, int B, int BLOCK>
   __device__ __forceinline__ void
-  family_passes(T *__restrict__ buf, const Mats<P> &m, int sl, int u, int v, bool act, uint32_t fm, bool transpose)
+  brick_constraint_passes(T *__restrict__ buf, const Mats<P> &m, int tid, int nslots, const uint32_t *__restrict__ fmask, bool transpose)
   {
-    constexpr int N  = 2 * P + 1;
-    constexpr int N3 = N * N * N;
-    constexpr int n  = P + 1;
-    const bool    xu = u == 0 || u == N - 1, xv = v == 0 || v == N - 1;
-    const int     su = u == N - 1, sv = v == N - 1;
+    using G               = Geo<P, B>;
+    constexpr int N       = G::N;
+    constexpr int N3      = G::N3;
+    constexpr int n       = P + 1;
+    constexpr int BC      = B / 2;      // parent cells per direction
+    constexpr int NCL     = P * BC + 1; // parent DoFs per line
+    constexpr int TOT     = G::SPW * G::LINES;
+    constexpr int ROUNDS  = (TOT + BLOCK - 1) / BLOCK;
+    // the masks of this thread's lines, loaded ONCE (a global load per direction and round would sit on the critical path)
+    uint32_t fmr[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r)
+      {
+        const int l = tid + r * BLOCK, sl = l / G::LINES;
+        fmr[r]      = (l < TOT && sl < nslots && fmask != nullptr) ? fmask[sl] : 0u;
+      }
 #pragma unroll
     for (int dd = 0; dd < 3; ++dd)
       {
         const int d = transpose ? 2 - dd : dd;
         // (u, v) are the coordinates in directions (e, f): d = 0: (y, z); d = 1: (x, z); d = 2: (x, y)
         const int e = d == 0 ? 1 : 0, f = d == 2 ? 1 : 2;
-        // edge along d at sides (s1 of (d+1)%3, s2 of (d+2)%3)
-        const int s1 = d == 1 ? sv : su, s2 = d == 1 ? su : sv;
-        const bool on = act && fm &&
-                        (((u == 0 && ((fm >> (2 * e)) & 1)) || (u == N - 1 && ((fm >> (2 * e + 1)) & 1)) ||
-                          (v == 0 && ((fm >> (2 * f)) & 1)) || (v == N - 1 && ((fm >> (2 * f + 1)) & 1))) ||
-                         (xu && xv && ((fm >> (6 + 4 * d + s1 + 2 * s2)) & 1)));
-        const int base   = d == 0 ? sl * N3 + (v * N + u) * N : (d == 1 ? sl * N3 + v * N * N + u : sl * N3 + v * N + u);
-        const int stride = d == 0 ? 1 : (d == 1 ? N : N * N);
-        if (on)
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r)
           {
-            if (!transpose)
+            const int  l = tid + r * BLOCK, sl = l / G::LINES, ln = l % G::LINES, u = ln % N, v = ln / N;
+            const uint32_t fm = fmr[r];
+            const bool     xu = u == 0 || u == N - 1, xv = v == 0 || v == N - 1;
+            const int  su = u == N - 1, sv = v == N - 1;
+            // edge along d at sides (s1 of (d+1)%3, s2 of (d+2)%3)
+            const int  s1 = d == 1 ? sv : su, s2 = d == 1 ? su : sv;
+            const bool on = fm != 0 &&
+                            (((u == 0 && ((fm >> (2 * e)) & 1)) || (u == N - 1 && ((fm >> (2 * e + 1)) & 1)) ||
+                              (v == 0 && ((fm >> (2 * f)) & 1)) || (v == N - 1 && ((fm >> (2 * f + 1)) & 1))) ||
+                             (xu && xv && ((fm >> (6 + 4 * d + s1 + 2 * s2)) & 1)));
+            const int base   = d == 0 ? sl * N3 + (v * N + u) * N : (d == 1 ? sl * N3 + v * N * N + u : sl * N3 + v * N + u);
+            const int stride = d == 0 ? 1 : (d == 1 ? N : N * N);
+            if (on)
               {
-                T in[n], out[N];
+                T line[N];
 #pragma unroll
-                for (int b = 0; b < n; ++b)
-                  in[b] = buf[base + (b < P ? b : N - 1) * stride];
-#pragma unroll
-                for (int a = 0; a < N; ++a)
+                for (int i = 0; i < N; ++i)
+                  line[i] = buf[base + i * stride];
+                if (!transpose)
                   {
-                    T acc = T(0);
+                    T par[NCL];
 #pragma unroll
-                    for (int b = 0; b < n; ++b)
-                      acc += T(a <= P ? m.I0[a * n + b] : m.I1[(a - P) * n + b]) * in[b];
-                    out[a] = acc;
+                    for (int k = 0; k < BC; ++k)
+#pragma unroll
+                      for (int b = 0; b < P; ++b)
+                        par[k * P + b] = line[2 * k * P + b];
+                    par[NCL - 1] = line[N - 1];
+#pragma unroll
+                    for (int k = 0; k < BC; ++k)
+#pragma unroll
+                      for (int a = (k == 0 ? 0 : 1); a <= 2 * P; ++a)
+                        {
+                          T acc = T(0);
+#pragma unroll
+                          for (int b = 0; b < n; ++b)
+                            acc += T(a <= P ? m.I0[a * n + b] : m.I1[(a - P) * n + b]) * par[k * P + b];
+                          buf[base + (2 * k * P + a) * stride] = acc;
+                        }
                   }
-#pragma unroll
-                for (int a = 0; a < N; ++a)
-                  buf[base + a * stride] = out[a];
-              }
-            else
-              {
-                T in[N], out[n];
-#pragma unroll
-                for (int a = 0; a < N; ++a)
-                  in[a] = buf[base + a * stride];
-#pragma unroll
-                for (int b = 0; b < n; ++b)
+                else
                   {
-                    T acc = T(0);
+                    T par[NCL];
 #pragma unroll
-                    for (int a = 0; a < N; ++a)
-                      acc += T(a <= P ? m.I0[a * n + b] : m.I1[(a - P) * n + b]) * in[a];
-                    out[b] = acc;
+                    for (int i = 0; i < NCL; ++i)
+                      par[i] = T(0);
+#pragma unroll
+                    for (int k = 0; k < BC; ++k)
+#pragma unroll
+                      for (int a = (k == 0 ? 0 : 1); a <= 2 * P; ++a) // a fine node shared by two parent cells counts once
+#pragma unroll
+                        for (int b = 0; b < n; ++b)
+                          par[k * P + b] += T(a <= P ? m.I0[a * n + b] : m.I1[(a - P) * n + b]) * line[2 * k * P + a];
+#pragma unroll
+                    for (int k = 0; k < BC; ++k)
+#pragma unroll
+                      for (int a = 0; a < 2 * P; ++a)
+                        buf[base + (2 * k * P + a) * stride] = a < P ? par[k * P + a] : T(0);
+                    buf[base + (N - 1) * stride] = par[NCL - 1];
                   }
-#pragma unroll
-                for (int a = 0; a < N; ++a)
-                  buf[base + a * stride] = a < P ? out[a] : (a == N - 1 ? out[P] : T(0));
               }
           }
         __syncthreads();
@@ -703,7 +740,7 @@ namespace mgamd
   // waves per SIMD: 2 for the 17^3 lattices (<= 256 VGPRs); 6 for single-cell slots (<= 80 VGPRs, measured 5 % faster at
   // p = 4 than unconstrained with 110 VGPRs)
   // the work of workgroup `block` of `nblocks` on the slots of args.g (kernels below)
-  template <typename T, int P, int B, int MODE>
+  template <typename T, int P, int B, int MODE, bool CONSTR = false>
   __device__ __forceinline__ void
   lattice_apply_body(const ApplyArgs<T, P> &args, const uint32_t block, const uint32_t nblocks, unsigned char *smem_raw)
   {
@@ -915,14 +952,19 @@ namespace mgamd
           hanging_passes<T, P>(bufA, args.m, sl, u, v, act, mask, false);
       }
 
-    uint32_t fm = 0;
-    if (B == 2)
+    // Which bricks may be constrained (must match LevelTables::build): families (B = 2) at every degree; larger bricks at
+    // P = 1 only, in a slot group and kernel instantiation of their own (CONSTR).  Measured on MI355X: at p = 1 the 16^3-cell rim bricks of the octant replace the 2.5x slower single-cell
+    // cluster path (V-cycle 1.95 -> 1.76 ms); at p = 4 the 4^3 rim bricks cost what the 2^3 families cost (0.5 vs 0.8 ns per
+    // cell, eaten by the passes), while the extra SGPR pressure of the pass code slowed EVERY 17^3 workgroup by 4-6 %.
+    if constexpr (brick_may_be_constrained(B, CONSTR))
       {
-        if (args.g.fmask != nullptr && act)
-          fm = args.g.fmask[slot0 + sl];
+        // constrained bricks: whole-face / whole-edge hanging nodes (uniform branch: one mask per slot)
+        uint32_t fm = 0;
+        if (args.g.fmask != nullptr && tid < nslots)
+          fm = args.g.fmask[slot0 + tid];
         any_hanging = __syncthreads_or((int)(fm != 0)) != 0;
         if (any_hanging)
-          family_passes<T, P>(bufA, args.m, sl, u, v, act, fm, false);
+          brick_constraint_passes<T, P, B, BLOCK>(bufA, args.m, tid, nslots, args.g.fmask + slot0, false);
       }
 
     if (!MGAMD_ABLATED(1))
@@ -930,8 +972,9 @@ namespace mgamd
 
     if (B == 1 && any_hanging)
       hanging_passes<T, P>(bufA, args.m, sl, u, v, act, mask, true);
-    if (B == 2 && any_hanging)
-      family_passes<T, P>(bufA, args.m, sl, u, v, act, fm, true);
+    if constexpr (brick_may_be_constrained(B, CONSTR))
+      if (any_hanging)
+        brick_constraint_passes<T, P, B, BLOCK>(bufA, args.m, tid, nslots, args.g.fmask + slot0, true);
     MGAMD_STAMP(2)
 
     // ---- interior DoFs are complete: fused epilogue, contiguous stores -----------------------------------
@@ -977,12 +1020,12 @@ namespace mgamd
 #undef MGAMD_STAMP
 #undef MGAMD_ABLATED
 
-  template <typename T, int P, int B, int MODE>
+  template <typename T, int P, int B, int MODE, bool CONSTR = false>
   __global__ void
   __launch_bounds__((Geo<P, B>::ABLOCK), (Geo<P, B>::ROUNDS > 1 ? 2 : (B == 1 ? 6 : 1))) lattice_apply_kernel(const ApplyArgs<T, P> args)
   {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    lattice_apply_body<T, P, B, MODE>(args, blockIdx.x, gridDim.x, smem_raw);
+    lattice_apply_body<T, P, B, MODE, CONSTR>(args, blockIdx.x, gridDim.x, smem_raw);
   }
 
   // The 2^3 bricks and the single cells of a level in ONE launch (both have 256-thread workgroups and 20-35 KB of LDS):
@@ -1250,7 +1293,7 @@ namespace mgamd
 
   // Diagonal of C^T K C.  Slots without hanging nodes: closed tensor form; single cells with hanging
   // faces/edges: one unit vector per local node through interpolation, sweeps and transpose.
-  template <typename T, int P, int B>
+  template <typename T, int P, int B, bool CONSTR = false>
   __global__ void
   __launch_bounds__((Geo<P, B>::BLOCK)) lattice_diag_kernel(const ApplyArgs<T, P> args)
   {
@@ -1329,13 +1372,13 @@ namespace mgamd
               __syncthreads();
             }
       }
-    if (B == 2)
+    if constexpr (brick_may_be_constrained(B, CONSTR))
       {
-        // constrained families: the parent DoFs on hanging faces/edges need (C^T A C)_jj: one unit vector per shell
+        // constrained bricks: the parent DoFs on hanging faces/edges need (C^T A C)_jj: one unit vector per shell
         // position through embedding, sweeps and transpose (the other shell entries reproduce the closed form)
         uint32_t fm = 0;
-        if (args.g.fmask != nullptr && act)
-          fm = args.g.fmask[slot0 + sl];
+        if (args.g.fmask != nullptr && tid < nslots)
+          fm = args.g.fmask[slot0 + tid];
         const bool any_family = __syncthreads_or((int)(fm != 0)) != 0;
         if (any_family)
           for (int s = 0; s < G::N_SHELL; ++s)
@@ -1344,10 +1387,10 @@ namespace mgamd
               for (int idx = tid; idx < G::SPW * G::N3; idx += G::BLOCK)
                 bufA[idx] = (idx % G::N3) == j ? T(1) : T(0);
               __syncthreads();
-              family_passes<T, P>(bufA, args.m, sl, u, v, act, fm, false);
+              brick_constraint_passes<T, P, B, G::BLOCK>(bufA, args.m, tid, nslots, args.g.fmask + slot0, false);
               lattice_sweeps<T, P, B, G::BLOCK>(bufA, bufB, args.m, tid, nslots, args.g.h + slot0);
-              family_passes<T, P>(bufA, args.m, sl, u, v, act, fm, true);
-              if (act && ln == 0 && fm)
+              brick_constraint_passes<T, P, B, G::BLOCK>(bufA, args.m, tid, nslots, args.g.fmask + slot0, true);
+              if (act && ln == 0 && args.g.fmask[slot0 + sl])
                 bufD[sl * G::N3 + j] = bufA[sl * G::N3 + j];
               __syncthreads();
             }

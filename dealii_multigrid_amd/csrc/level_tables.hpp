@@ -19,6 +19,7 @@
 //    the 1D matrices FE1D::I[c]; its configuration is Tria::masks.
 #pragma once
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdlib>
 #include "fe1d.hpp"
@@ -99,10 +100,13 @@ namespace mgamd
     std::vector<uint32_t> interior_base; // per slot: global index of its first interior DoF
     std::vector<uint32_t> shell_idx;     // per slot x n_shell: global DoF or INVALID_DOF (Dirichlet)
     std::vector<uint16_t> mask;          // per slot: constraint configuration (0 for bricks)
-    std::vector<uint32_t> fmask;         // B == 2 only, per slot: hanging faces/edges of the whole family (family_* helpers), 0 = none
+    std::vector<uint32_t> fmask;         // bricks (B >= 2), per slot: hanging faces/edges of the whole brick (family_* helpers), 0 = none
     std::vector<double>   h;             // per slot: cell edge length
     std::vector<uint32_t> first_cell;    // per slot: index of its first cell in Tria::cells
     std::vector<uint16_t> shell_pos;     // n_shell: lattice index (z*N+y)*N+x of each shell entry
+    // p = 1, B > 2: the constrained bricks form a group of their own (their kernel carries the embedding passes; the
+    // unconstrained bricks keep the lean kernel).  Families (B = 2) share the group of the 2^3 bricks.
+    bool constrained_group = false;
     size_t
     n_slots() const
     {
@@ -184,12 +188,13 @@ namespace mgamd
   {
     return (fm >> (6 + 4 * d + s1 + 2 * s2)) & 1;
   }
-  // lattice node n (coordinates 0..2p) of a family: does it lie on a hanging face/edge?  pinned[d]: the coordinate
-  // is fixed by the hanging entity (its parent coordinate is 0 or p), otherwise it runs along the entity
+  // lattice node n (coordinates 0..B p) of a constrained brick: does it lie on a hanging face/edge?  pinned[d]: the
+  // coordinate is fixed by the hanging entity (its parent coordinate is 0 or p of the outermost parent cell), otherwise it
+  // runs along the entity
   inline bool
-  family_node_constrained(uint32_t fm, int p, const int n[3], bool pinned[3])
+  family_node_constrained(uint32_t fm, int p, int B, const int n[3], bool pinned[3])
   {
-    const int N1 = 2 * p;
+    const int N1 = B * p;
     bool      any = false;
     for (int d = 0; d < 3; ++d)
       {
@@ -209,37 +214,59 @@ namespace mgamd
       }
     return false;
   }
-  // family mask from the children's cell masks (child index = position bits); false if they do not describe
-  // whole-family faces/edges
+  // Constrained BRICKS of any size (B = 2: a family).  A brick of B^3 equal cells next to coarser cells qualifies if the
+  // hanging entities are WHOLE faces / WHOLE edges of the brick: a hanging brick face then is (B/2)^2 faces of parent-size
+  // cells and carries the parents' (p B/2 + 1)^2 DoFs.  Along a lattice line the parent DoF k p + c (parent cell k, local
+  // coordinate c) is stored at lattice coordinate 2 k p + c for c < p (c = p: the next parent cell's c = 0, or B p at the end);
+  // the other positions of the entity carry no DoF and are filled by the in-place embedding E = [I0; I1] per parent cell.
+  // mask of the brick from its cells: bpos[c] = position of cell c inside the brick, cm[c] = its cell mask; false if the
+  // cells do not describe whole-face / whole-edge constraints
   inline bool
-  family_mask_from_children(const uint16_t cm[8], int p, uint32_t &fm)
+  brick_mask_from_cells(int B, int p, const std::vector<std::array<int, 3>> &bpos, const std::vector<uint16_t> &cm, uint32_t &fm)
   {
     fm = 0;
-    for (int c = 0; c < 8; ++c)
+    const size_t nc = bpos.size();
+    for (size_t c = 0; c < nc; ++c)
       {
-        const int cp[3] = {c & 1, (c >> 1) & 1, (c >> 2) & 1};
-        if ((cm[c] & 7) != c)
+        const int cp[3] = {bpos[c][0] & 1, bpos[c][1] & 1, bpos[c][2] & 1};
+        if ((cm[c] & 7) != (cp[0] | (cp[1] << 1) | (cp[2] << 2)))
           return false;
+        bool out[3]; // is the parent-side face of this cell in direction d on the brick boundary?
+        for (int d = 0; d < 3; ++d)
+          out[d] = bpos[c][d] == (cp[d] ? B - 1 : 0);
         for (int d = 0; d < 3; ++d)
           {
             if ((cm[c] >> (MASK_FACE_SHIFT + d)) & 1)
-              fm |= 1u << (2 * d + cp[d]);
+              {
+                if (!out[d])
+                  return false;
+                fm |= 1u << (2 * d + cp[d]);
+              }
             if ((cm[c] >> (MASK_EDGE_SHIFT + d)) & 1)
-              fm |= 1u << (6 + 4 * d + cp[(d + 1) % 3] + 2 * cp[(d + 2) % 3]);
+              {
+                const int e = (d + 1) % 3, f = (d + 2) % 3;
+                // an edge bit that only mirrors a hanging face of this cell needs no edge of its own
+                const bool fe = (cm[c] >> (MASK_FACE_SHIFT + e)) & 1, ff = (cm[c] >> (MASK_FACE_SHIFT + f)) & 1;
+                if (fe || ff)
+                  continue;
+                if (!out[e] || !out[f])
+                  return false;
+                fm |= 1u << (6 + 4 * d + cp[e] + 2 * cp[f]);
+              }
           }
       }
-    // every child must see exactly the constraints the family mask implies
-    for (int c = 0; c < 8; ++c)
+    // every cell must see exactly the constraints the brick mask implies
+    for (size_t c = 0; c < nc; ++c)
       {
-        const int cp[3] = {c & 1, (c >> 1) & 1, (c >> 2) & 1};
+        const int cp[3] = {bpos[c][0] & 1, bpos[c][1] & 1, bpos[c][2] & 1};
         for (int z = 0; z <= p; ++z)
           for (int y = 0; y <= p; ++y)
             for (int x = 0; x <= p; ++x)
               {
-                const int a[3] = {x, y, z};
-                const int n[3] = {cp[0] * p + x, cp[1] * p + y, cp[2] * p + z};
-                bool      pinned[3];
-                const bool fam = family_node_constrained(fm, p, n, pinned);
+                const int  a[3] = {x, y, z};
+                const int  n[3] = {bpos[c][0] * p + x, bpos[c][1] * p + y, bpos[c][2] * p + z};
+                bool       pinned[3];
+                const bool fam  = family_node_constrained(fm, p, B, n, pinned);
                 bool       cell = false;
                 if (cm[c] >> MASK_FACE_SHIFT)
                   {
@@ -256,15 +283,29 @@ namespace mgamd
       }
     return true;
   }
-  // the embedding (transpose = false) or its transpose on a (2p+1)^3 family lattice, host version
+  // lattice coordinate -> does a parent DoF live there along a free direction, and which (parent cell k, local c)?
+  inline bool
+  family_parent_position(int p, int B, int n, int &k, int &c)
+  {
+    if (n == B * p)
+      {
+        k = B / 2 - 1;
+        c = p;
+        return true;
+      }
+    k = n / (2 * p);
+    c = n % (2 * p);
+    return c < p;
+  }
+  // the embedding (transpose = false) or its transpose on the (B p + 1)^3 lattice of a constrained brick, host version
   inline void
-  interpolate_family(const FE1D &fe, uint32_t fm, double *v, bool transpose)
+  interpolate_family(const FE1D &fe, int B, uint32_t fm, double *v, bool transpose)
   {
     if (!fm)
       return;
-    const int p = fe.p, n = p + 1, N = 2 * p + 1;
+    const int p = fe.p, n = p + 1, N = B * p + 1, BC = B / 2;
     const int stride[3] = {1, N, N * N};
-    double    in[2 * MAX_DEGREE + 1], out[2 * MAX_DEGREE + 1];
+    std::vector<double> in(N), out(N);
     auto      E = [&](int a, int b) { return a <= p ? fe.I[0][a * n + b] : fe.I[1][(a - p) * n + b]; };
     for (int dd = 0; dd < 3; ++dd)
       {
@@ -281,25 +322,23 @@ namespace mgamd
               double *line = v + ae * stride[e] + af * stride[f];
               for (int i = 0; i < N; ++i)
                 in[i] = line[i * stride[d]];
-              if (!transpose)
-                for (int a = 0; a < N; ++a)
-                  {
-                    double s = 0;
-                    for (int b = 0; b < n; ++b)
-                      s += E(a, b) * in[b < p ? b : N - 1];
-                    out[a] = s;
-                  }
-              else
+              for (int i = 0; i < N; ++i)
+                out[i] = 0;
+              for (int k = 0; k < BC; ++k)
                 {
-                  for (int i = 0; i < N; ++i)
-                    out[i] = 0;
-                  for (int b = 0; b < n; ++b)
-                    {
-                      double s = 0;
-                      for (int a = 0; a < N; ++a)
-                        s += E(a, b) * in[a];
-                      out[b < p ? b : N - 1] = s;
-                    }
+                  auto pos = [&](int b) { return 2 * k * p + (b < p ? b : 2 * p); }; // parent DoF b of parent cell k
+                  if (!transpose)
+                    for (int a = 0; a <= 2 * p; ++a)
+                      {
+                        double s = 0;
+                        for (int b = 0; b < n; ++b)
+                          s += E(a, b) * in[pos(b)];
+                        out[2 * k * p + a] = s; // the node shared with the next parent cell gets the same value twice
+                      }
+                  else
+                    for (int a = (k == 0 ? 0 : 1); a <= 2 * p; ++a) // a fine node shared by two parent cells counts once
+                      for (int b = 0; b < n; ++b)
+                        out[pos(b)] += E(a, b) * in[2 * k * p + a];
                 }
               for (int i = 0; i < N; ++i)
                 line[i * stride[d]] = out[i];
@@ -437,9 +476,9 @@ namespace mgamd
       const uint16_t   mask = tria->masks[ci];
       if (constrained)
         *constrained = (mask >> MASK_FACE_SHIFT) ? node_on_constrained_entity(mask, p, a, parent_corner) : false;
-      if (g.B == 2 && g.fmask[s] && (mask >> MASK_FACE_SHIFT) && node_on_constrained_entity(mask, p, a))
+      if (g.B >= 2 && g.fmask[s] && (mask >> MASK_FACE_SHIFT) && node_on_constrained_entity(mask, p, a))
         {
-          // cell of a constrained family: the parent entity's DoF, as for a single cell
+          // cell of a constrained brick: the parent entity's DoF, as for a single cell
           const int32_t *idx = keymap.find(resolved_key(ci, a));
           if (!idx)
             throw std::runtime_error("constrained family: parent DoF not numbered");
@@ -519,8 +558,8 @@ namespace mgamd
                     loc[(z * N + y) * N + x] = h3 * m1[x] * m1[y] * m1[z];
               if (g.B == 1)
                 interpolate_hanging(fe, g.mask[s], loc.data(), true);
-              else if (g.B == 2 && g.fmask[s])
-                interpolate_family(fe, g.fmask[s], loc.data(), true);
+              else if (g.B >= 2 && g.fmask[s])
+                interpolate_family(fe, g.B, g.fmask[s], loc.data(), true);
               for (int z = 0; z < N; ++z)
                 for (int y = 0; y < N; ++y)
                   for (int x = 0; x < N; ++x)
@@ -775,12 +814,25 @@ namespace mgamd
       // lattice kernel on small lattices and saves a launch per size and application (octant, 17 M DoFs, measured:
       // sizes {16,8,4,2,1} 2.93 ms per V-cycle, {16,8,4,1} 2.66, later {16,8,4,1} 2.31, {16,8,1} 2.23, {16,1} 2.29)
       const bool hanging_bricks = getenv("MGAMD_NO_HANGING_BRICKS") == nullptr;
+      // MGAMD_MAX_CONSTRAINED_BRICK=2: only families (the 8 children of one cell) may be constrained bricks (development A/B)
+      // (larger constrained bricks only at p = 1: kernels.hpp brick_may_be_constrained, with the measurements)
+      const int  max_constrained_brick =
+        p != 1 ? 2 : (getenv("MGAMD_MAX_CONSTRAINED_BRICK") ? std::max(2, atoi(getenv("MGAMD_MAX_CONSTRAINED_BRICK"))) : 1 << 30);
       int        skip           = p == 1 ? 6 : 0;
       if (const char *e = getenv("MGAMD_SKIP_BRICKS")) // development: bit mask of brick sizes to leave out
         skip = atoi(e);
+      std::vector<bool> constrained_only;
       for (int B = Bmax; B >= 1; B /= 2)
         if (B == 1 || B == Bmax || !(skip & B))
-          sizes.push_back(B);
+          {
+            sizes.push_back(B);
+            constrained_only.push_back(false);
+            if (B > 2 && hanging_bricks && B <= max_constrained_brick)
+              { // second group of this size for the constrained bricks
+                sizes.push_back(B);
+                constrained_only.push_back(true);
+              }
+          }
       groups.resize(sizes.size());
       cell_group.assign(nc, 0xFF);
       cell_slot.assign(nc, 0);
@@ -791,7 +843,8 @@ namespace mgamd
       for (size_t gi = 0; gi < sizes.size(); ++gi)
         {
           SlotGroup &g = groups[gi];
-          g.B          = sizes[gi];
+          g.B                 = sizes[gi];
+          g.constrained_group = constrained_only[gi];
           g.N          = p * g.B + 1;
           g.n_interior = (g.N - 2) * (g.N - 2) * (g.N - 2);
           g.n_shell    = g.N * g.N * g.N - g.n_interior;
@@ -832,21 +885,25 @@ namespace mgamd
                     }
                   if (ok && hanging)
                     {
-                      // a family with hanging faces/edges can still be a (constrained) 2^3 brick
+                      // a brick whose hanging entities are whole faces / whole edges stays a (constrained) brick
                       ok = false;
-                      if (B == 2 && hanging_bricks && c.level >= 1)
+                      if (hanging_bricks && B <= max_constrained_brick && c.level >= 1)
                         {
-                          uint16_t cm[8];
-                          bool     morton = true;
-                          for (int s = 0; s < 8; ++s)
+                          std::vector<std::array<int, 3>> bpos(B3);
+                          std::vector<uint16_t>           cm(B3);
+                          for (size_t s2 = 0; s2 < B3; ++s2)
                             {
-                              const Cell &d = cells[t + s];
-                              cm[s]         = masks[t + s];
-                              morton &= (int)((d.i & 1) | ((d.j & 1) << 1) | ((d.k & 1) << 2)) == s;
+                              const Cell &d = cells[t + s2];
+                              bpos[s2]      = {(int)(d.i - c.i), (int)(d.j - c.j), (int)(d.k - c.k)};
+                              cm[s2]        = masks[t + s2];
                             }
-                          ok = morton && family_mask_from_children(cm, p, fm);
+                          ok = brick_mask_from_cells(B, p, bpos, cm, fm);
                         }
                     }
+                  // B > 2: constrained bricks only into the constrained group of this size, the others into the plain one
+                  // (the plain group is scanned first; an unclaimed constrained brick is picked up by the next group)
+                  if (ok && B > 2 && (fm != 0) != g.constrained_group)
+                    ok = false;
                 }
               if (!ok)
                 {
@@ -856,7 +913,7 @@ namespace mgamd
               const uint32_t slot = (uint32_t)g.first_cell.size();
               g.first_cell.push_back((uint32_t)t);
               g.mask.push_back(B == 1 ? masks[t] : 0);
-              if (B == 2)
+              if (B >= 2)
                 g.fmask.push_back(fm);
               g.h.push_back(2.0 / (double)(1u << c.level));
               for (size_t s = 0; s < B3; ++s)
@@ -957,26 +1014,34 @@ namespace mgamd
               uint64_t key;
               if (g.B == 1)
                 key = resolved_key(ci, a);
-              else if (g.B == 2 && g.fmask[r.slot])
+              else if (g.B >= 2 && g.fmask[r.slot])
                 {
-                  // hanging face/edge of a family: parent coordinate c sits at lattice coordinate c (c < p) or 2p (c = p),
-                  // the other lattice positions carry no DoF (filled by the embedding)
+                  // hanging face/edge of a constrained brick: the parent DoF k p + c of parent cell k sits at lattice
+                  // coordinate 2 k p + c (c < p; c = p: B p at the far end); the other lattice positions carry no DoF (filled
+                  // by the embedding)
                   bool pinned[3];
-                  if (family_node_constrained(g.fmask[r.slot], p, a, pinned))
+                  if (family_node_constrained(g.fmask[r.slot], p, g.B, a, pinned))
                     {
-                      int  ap[3];
+                      int  ap[3], kc[3];
                       bool dof = true;
                       for (int d = 0; d < 3; ++d)
                         {
-                          ap[d] = (pinned[d] || a[d] == 2 * p) ? (a[d] ? p : 0) : a[d];
-                          dof &= pinned[d] || a[d] < p || a[d] == 2 * p;
+                          if (pinned[d])
+                            {
+                              kc[d] = a[d] ? g.B / 2 - 1 : 0;
+                              ap[d] = a[d] ? p : 0;
+                            }
+                          else
+                            dof &= family_parent_position(p, g.B, a[d], kc[d], ap[d]);
                         }
                       if (!dof)
                         {
                           g.shell_idx[(size_t)r.slot * g.n_shell + s] = INVALID_DOF;
                           continue;
                         }
-                      key = own_key(Cell{c.i >> 1, c.j >> 1, c.k >> 1, (uint8_t)(c.level - 1)}, ap);
+                      key = own_key(Cell{(anchor.i >> 1) + (uint32_t)kc[0], (anchor.j >> 1) + (uint32_t)kc[1], (anchor.k >> 1) + (uint32_t)kc[2],
+                                         (uint8_t)(c.level - 1)},
+                                    ap);
                     }
                   else
                     key = own_key(anchor, a);

@@ -298,7 +298,7 @@ namespace mgamd
       HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
 
-  template <typename T, int P, int B, int MODE>
+  template <typename T, int P, int B, int MODE, bool CONSTR = false>
   static void
   launch_lattice(Ctx *ctx, hipStream_t st, const ApplyArgs<T, P> &a, bool diag)
   {
@@ -309,24 +309,36 @@ namespace mgamd
     if (diag)
       {
         const size_t lds  = 3 * (size_t)G::SPW * G::N3 * sizeof(T);
-        auto         kern = lattice_diag_kernel<T, P, B>;
+        auto         kern = lattice_diag_kernel<T, P, B, CONSTR>;
         ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), lds);
         hipLaunchKernelGGL(kern, grid, G::BLOCK, lds, st, a);
       }
     else
       {
         const size_t lds  = (2 * (size_t)G::SPW * G::N3 + 2 * P * P * P + G::SPW) * sizeof(T);
-        auto         kern = lattice_apply_kernel<T, P, B, MODE>;
+        auto         kern = lattice_apply_kernel<T, P, B, MODE, CONSTR>;
         ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), lds);
         hipLaunchKernelGGL(kern, grid, G::ABLOCK, lds, st, a);
       }
     HIP_CHECK(hipGetLastError());
   }
 
+  // constrained = the group of constrained bricks larger than a family (p = 1 only, LevelTables::build)
   template <typename T, int P, int MODE>
   static void
-  dispatch_B(Ctx *ctx, hipStream_t st, int B, const ApplyArgs<T, P> &a, bool diag)
+  dispatch_B(Ctx *ctx, hipStream_t st, int B, bool constrained, const ApplyArgs<T, P> &a, bool diag)
   {
+    if (constrained)
+      {
+        if constexpr (P == 1)
+          {
+            if (B == 8)
+              return launch_lattice<T, P, 8, MODE, true>(ctx, st, a, diag);
+            if (B == 16)
+              return launch_lattice<T, P, 16, MODE, true>(ctx, st, a, diag);
+          }
+        throw std::runtime_error("constrained bricks of this size/degree are not instantiated");
+      }
     switch (B)
       {
         case 1:
@@ -368,6 +380,7 @@ namespace mgamd
   struct GroupDev
   {
     int            B = 1, N = 2;
+    bool           constrained = false; // the group of constrained bricks larger than a family
     size_t         n_slots = 0;
     DBuf<uint32_t> interior_base, shell_idx;
     DBuf<uint16_t> mask, shell_pos;
@@ -483,8 +496,9 @@ namespace mgamd
       for (const SlotGroup &g : tables->groups)
         {
           auto d     = std::make_unique<GroupDev<T>>();
-          d->B       = g.B;
-          d->N       = g.N;
+          d->B           = g.B;
+          d->N           = g.N;
+          d->constrained = g.constrained_group;
           d->n_slots = g.n_slots();
           if (d->n_slots)
             {
@@ -649,7 +663,7 @@ namespace mgamd
                  const T *src, const Epilogue<T> &epi, bool diag, size_t begin, size_t end)
     {
       a.g      = (begin == 0 && end == g->n_slots) ? g->view() : g->view(begin, end);
-      a.stamps = (stamps.p && g->B == prof_B && MODE == stamp_mode && !diag && begin == 0) ? stamps.p : nullptr;
+      a.stamps = (stamps.p && g->B == prof_B && !g->constrained && MODE == stamp_mode && !diag && begin == 0) ? stamps.p : nullptr;
       if (partner_clusters)
         {
           if constexpr (P == 1)
@@ -687,7 +701,7 @@ namespace mgamd
             }
         }
       else
-        dispatch_B<T, P, MODE>(ctx, st, g->B, a, diag);
+        dispatch_B<T, P, MODE>(ctx, st, g->B, g->constrained, a, diag);
     }
 
     template <int MODE>
@@ -756,7 +770,7 @@ namespace mgamd
       if (P == 1 && !diag && merge_small)
         for (auto &g : groups)
           {
-            if (g->n_slots && g->B == 8 && g->B != prof_B)
+            if (g->n_slots && g->B == 8 && g->B != prof_B && !g->constrained)
               g8 = g.get();
             else if (g->n_slots && g->B == 1 && g->has_clusters())
               gc = g.get();
@@ -769,7 +783,7 @@ namespace mgamd
       if (pipelined)
         ctx->order_after(side, main); // the side queue starts where the main queue stands
       auto prof_begin = [&](const GroupDev<T> &g) {
-        const bool prof = ctx->profile && !diag && MODE == MODE_CHEB && g.B == (ctx->prof_brick ? ctx->prof_brick : prof_B);
+        const bool prof = ctx->profile && !diag && MODE == MODE_CHEB && !g.constrained && g.B == (ctx->prof_brick ? ctx->prof_brick : prof_B);
         if (prof)
           {
             if (ctx->prof_used == ctx->prof_events.size())

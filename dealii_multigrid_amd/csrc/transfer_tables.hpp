@@ -82,8 +82,8 @@ namespace mgamd
             const int Bc  = fg.B / 2;
             for (size_t s = 0; s < fg.n_slots(); ++s)
               {
-                if (fg.B == 2 && fg.fmask[s])
-                  continue; // constrained family: per-cell patches handle its hanging nodes
+                if (fg.fmask[s])
+                  continue; // constrained brick: per-cell patches handle its hanging nodes
                 const Cell &fc = tf.cells[fg.first_cell[s]];
                 const Cell  anchor{fc.i & ~(uint32_t)(fg.B - 1), fc.j & ~(uint32_t)(fg.B - 1), fc.k & ~(uint32_t)(fg.B - 1), fc.level};
                 // all parents must be hanging-node-free leaves of the coarse mesh; otherwise (cells not coarsened on
