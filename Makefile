@@ -43,3 +43,8 @@ clean:
 debug:
 	$(MAKE) LIBDIR=dealii_multigrid_amd/lib_debug DEBUGFLAGS=-DMGAMD_KERNEL_DEBUG dealii_multigrid_amd/lib_debug/libmgamd.so
 .PHONY: debug
+
+# micro-benchmark behind DESIGN.md's "MFMA only where it pays" statement (tools/mfma_probe.hip)
+tools/bin/mfma_probe: tools/mfma_probe.hip $(HDRS)
+	@mkdir -p tools/bin
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -I$(CSRC) -Iinclude $< -o $@
