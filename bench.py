@@ -136,7 +136,9 @@ def pmc_traffic(n_ref, B):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_traffic_octant{n_ref}_p4.json")))
     if not files:
         return None, None
-    rows = [r for r in json.load(open(files[-1]))["kernels"] if f"lattice_apply_kernel<double, 4, {B}, 2>" in r["kernel"]]
+    rows = [r for r in json.load(open(files[-1]))["kernels"] if f"lattice_apply_kernel<double, 4, {B}, 2" in r["kernel"]]
+    for r in rows:  # tools/pmc_vcycle.py (round 2) counts launches per V-cycle, tools/pmc_summary.py (round 1) per run
+        r.setdefault("launches", r.get("launches_per_cycle", 0))
     n = sum(r["launches"] for r in rows)
     src = os.path.relpath(files[-1], ROOT)
     try:
@@ -306,6 +308,9 @@ def main():
                 if mode == "sharded" else f"replicas x{world} (no data-path collective)"),
             "cg_iterations_reltol_1e-4": prim["cg_iterations"],
             "cg_throughput_dofs_x_iterations_per_s": prim["cg_throughput"],
+            "chebyshev_start_vector": "deal.II's (i mod 11) - mean on the local numbering" if world == 1 or mode == "replicas" else
+                                      "sharded run: numbering-independent hash of the geometric DoF key (mod 11) - mean; a 1-GPU run uses "
+                                      "the index-based vector, so eigenvalue estimates (and borderline CG counts) can differ slightly",
         },
     }
     if "ms_no_collapse" in prim:

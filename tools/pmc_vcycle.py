@@ -47,11 +47,12 @@ for (k, g), (rd, wr, n) in sorted(agg.items(), key=lambda kv: -(kv[1][0] + kv[1]
     rows.append({"kernel": k, "workgroups": g, "launches_per_cycle": n / cycles, "read_bytes_per_launch": rd / n, "write_bytes_per_launch": wr / n,
                  "hbm_bytes_per_launch": (rd + wr) / n, "hbm_bytes_per_cycle": (rd + wr) / cycles})
 tot = sum(r["hbm_bytes_per_cycle"] for r in rows)
-# the calibration dispatches of vcycle_trace.py are the largest vec_sadd launches of the run (32 M doubles)
+# calibration on the LARGEST vec_sadd launch of the run (y = s y + a x on n doubles reads 16 n bytes and writes 8 n: the
+# finest-level update of the eigenvalue-estimation CG, or the 32 M-double calibration launches of vcycle_trace.py)
 summary = {"note": __doc__, "cycles": cycles, "hbm_bytes_per_cycle_total": tot,
            "calibration_vec_sadd": {"read_over_write": (max(cal_r) / max(cal_w)) if cal_r and cal_w else None,
-                                    "read_bytes": max(cal_r) if cal_r else None, "expected_read_bytes": 16.0 * (1 << 25),
-                                    "write_bytes": max(cal_w) if cal_w else None, "expected_write_bytes": 8.0 * (1 << 25)},
+                                    "read_bytes": max(cal_r) if cal_r else None, "write_bytes": max(cal_w) if cal_w else None,
+                                    "expected": "read = 2 x write = 16 B x n"},
            "kernels": rows}
 json.dump(summary, open(out, "w"), indent=1)
 print(f"HBM bytes per cycle: {tot/1e9:.3f} GB; calibration {summary['calibration_vec_sadd']}")
