@@ -614,6 +614,26 @@ class Hierarchy:
             self._build_local_smoothing(ctx, fine, degree, smoother_degree, smoothing_range, eig_cg_n_iterations, coarse_solver, number_type,
                                         max_brick)
             return
+        elif mg_type == "HPMG-local":
+            # ref:multigrid_throughput.cc:1685-1695,1846-1860: p-multigrid on the active mesh whose coarse problem (lowest degree)
+            # is handed to ONE local-smoothing V-cycle (MGCoarseGridApplyPreconditioner of the intermediate PreconditionMG)
+            pseq = create_polynomial_coarsening_sequence(degree)
+            self._build_local_smoothing(ctx, fine, pseq[0], smoother_degree, smoothing_range, eig_cg_n_iterations, coarse_solver, number_type,
+                                        max_brick)
+            if len(pseq) == 1:
+                return
+            self.ls = dict(trias=self.trias, dofs=self.dofs, operators=self.operators, transfers=self.transfers, smoothers=self.smoothers,
+                           mg=self.mg)
+            self.trias = [fine] * len(pseq)
+            self.degrees = pseq
+            self.dofs = [self.active_dofs] + [DoFs(fine, p, max_brick) for p in pseq[1:]]
+            self.operators = [Operator(ctx, d, number_type) for d in self.dofs]
+            self.transfers = [None] + [MGTwoLevelTransfer(self.operators[l], self.operators[l - 1]) for l in range(1, len(self.dofs))]
+            self.smoothers = [PreconditionChebyshev(op, smoother_degree, smoothing_range, eig_cg_n_iterations) for op in self.operators]
+            self.mg = PreconditionMG(ctx, self.operators, self.transfers, self.smoothers, "gmg_vcycle", self.ls["mg"], 1)
+            self.fine_operator = self.operators[-1] if number_type == F64 else Operator(ctx, self.dofs[-1], F64)
+            self.n_dofs = self.dofs[-1].n_dofs
+            return
         else:
             raise MgamdError(f"Type '{mg_type}' not implemented")
         # max_brick=-1: bricks on large levels, single-cell slots on the latency-bound small ones (level_tables.hpp)

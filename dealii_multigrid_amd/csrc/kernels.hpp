@@ -2027,6 +2027,35 @@ namespace mgamd
     const uint32_t brick = xcd_contiguous(blockIdx.x, gridDim.x);
     const uint32_t slot  = args.slot[brick];
 
+    // operands of the final read-modify-write of dst: requested now, consumed after the sweeps (the barriers in between
+    // wait on LDS traffic only, so these loads stay in flight under the embedding arithmetic)
+    constexpr int  NI_P  = LG::NI > 0 ? LG::NI : 1;
+    constexpr int  NIN_P = LG::N_INT > 0 ? LG::N_INT : 1;
+    constexpr int  ITI_P = (NIN_P + BLOCK - 1) / BLOCK;
+    constexpr int  ITS_P = (LG::N_SHELL + BLOCK - 1) / BLOCK;
+    const uint32_t ibase = LG::N_INT > 0 ? args.interior_base[slot] : 0u;
+    T              ival[ITI_P];
+    uint32_t       sgi_p[ITS_P];
+    T              sval_p[ITS_P];
+    if (LG::N_INT > 0)
+      {
+#pragma unroll
+        for (int it = 0; it < ITI_P; ++it)
+          {
+            const int i = tid + it * BLOCK;
+            ival[it]    = args.dst[ibase + (i < NIN_P ? i : 0)];
+          }
+      }
+#pragma unroll
+    for (int it = 0; it < ITS_P; ++it)
+      {
+        const int s = tid + it * BLOCK;
+        sgi_p[it]   = s < LG::N_SHELL ? args.own_shell[(size_t)brick * LG::N_SHELL + s] : DEV_INVALID;
+      }
+#pragma unroll
+    for (int it = 0; it < ITS_P; ++it)
+      sval_p[it] = args.dst[sgi_p[it] != DEV_INVALID ? sgi_p[it] : 0];
+
     {
       constexpr int ITC = (G::NC3 + BLOCK - 1) / BLOCK;
       uint32_t      gi[ITC];
@@ -2092,49 +2121,24 @@ namespace mgamd
           buf[base + i] = out[i];
       }
     __syncthreads();
-    // dst += : interior contiguous, then the owned shell
+    // dst += : interior contiguous, then the owned shell (old values already in registers)
     if (LG::N_INT > 0)
       {
-        constexpr int  NI_  = LG::NI > 0 ? LG::NI : 1;
-        constexpr int  NIN_ = LG::N_INT > 0 ? LG::N_INT : 1;
-        constexpr int  ITI  = (NIN_ + BLOCK - 1) / BLOCK;
-        const uint32_t base = args.interior_base[slot];
-        T              val[ITI];
 #pragma unroll
-        for (int it = 0; it < ITI; ++it)
+        for (int it = 0; it < ITI_P; ++it)
           {
             const int i = tid + it * BLOCK;
-            val[it]     = args.dst[base + (i < NIN_ ? i : 0)];
-          }
-#pragma unroll
-        for (int it = 0; it < ITI; ++it)
-          {
-            const int i = tid + it * BLOCK;
-            if (i < NIN_)
+            if (i < NIN_P)
               {
-                const int x = i % NI_, y = (i / NI_) % NI_, z = i / (NI_ * NI_);
-                args.dst[base + i] = val[it] + buf[((z + 1) * NF + (y + 1)) * NF + x + 1];
+                const int x = i % NI_P, y = (i / NI_P) % NI_P, z = i / (NI_P * NI_P);
+                args.dst[ibase + i] = ival[it] + buf[((z + 1) * NF + (y + 1)) * NF + x + 1];
               }
           }
       }
-    {
-      constexpr int ITS = (LG::N_SHELL + BLOCK - 1) / BLOCK;
-      uint32_t      gi[ITS];
-      T             val[ITS];
 #pragma unroll
-      for (int it = 0; it < ITS; ++it)
-        {
-          const int s = tid + it * BLOCK;
-          gi[it]      = s < LG::N_SHELL ? args.own_shell[(size_t)brick * LG::N_SHELL + s] : DEV_INVALID;
-        }
-#pragma unroll
-      for (int it = 0; it < ITS; ++it)
-        val[it] = args.dst[gi[it] != DEV_INVALID ? gi[it] : 0];
-#pragma unroll
-      for (int it = 0; it < ITS; ++it)
-        if (gi[it] != DEV_INVALID)
-          args.dst[gi[it]] = val[it] + buf[args.shell_pos[tid + it * BLOCK]];
-    }
+    for (int it = 0; it < ITS_P; ++it)
+      if (sgi_p[it] != DEV_INVALID)
+        args.dst[sgi_p[it]] = sval_p[it] + buf[args.shell_pos[tid + it * BLOCK]];
   }
 
   template <typename T, int P, int B>
@@ -2193,6 +2197,23 @@ namespace mgamd
         if (tid + it * BLOCK < LG::N_SHELL)
           buf[args.shell_pos[tid + it * BLOCK]] = gi[it] != DEV_INVALID ? val[it] : T(0);
     }
+    // the coarse indices and the old values of the patch-interior coarse nodes (plain read-modify-write at the end):
+    // requested before the sweeps
+    constexpr int ITC_R = (G::NC3 + BLOCK - 1) / BLOCK;
+    uint32_t      cgi[ITC_R];
+    T             cold[ITC_R];
+    bool          cinner[ITC_R];
+#pragma unroll
+    for (int it = 0; it < ITC_R; ++it)
+      {
+        const int idx = tid + it * BLOCK;
+        cgi[it]       = idx < G::NC3 ? args.coarse_idx[(size_t)brick * G::NC3 + idx] : DEV_INVALID;
+        const int x = idx % NC, y = (idx / NC) % NC, z = idx / (NC * NC);
+        cinner[it] = x > 0 && y > 0 && z > 0 && x < NC - 1 && y < NC - 1 && z < NC - 1;
+      }
+#pragma unroll
+    for (int it = 0; it < ITC_R; ++it)
+      cold[it] = args.dst[(cgi[it] != DEV_INVALID && cinner[it]) ? cgi[it] : 0];
     __syncthreads();
     T in[NF], out[NC];
     // x^T: lines (Y, Z)
@@ -2234,35 +2255,18 @@ namespace mgamd
           buf[base + i * NF * NF] = out[i];
       }
     __syncthreads();
-    {
-      constexpr int ITC = (G::NC3 + BLOCK - 1) / BLOCK;
-      uint32_t      gi[ITC];
-      T             old[ITC];
-      bool          inner[ITC];
 #pragma unroll
-      for (int it = 0; it < ITC; ++it)
+    for (int it = 0; it < ITC_R; ++it)
+      if (cgi[it] != DEV_INVALID)
         {
           const int idx = tid + it * BLOCK;
-          gi[it]        = idx < G::NC3 ? args.coarse_idx[(size_t)brick * G::NC3 + idx] : DEV_INVALID;
           const int x = idx % NC, y = (idx / NC) % NC, z = idx / (NC * NC);
-          inner[it] = x > 0 && y > 0 && z > 0 && x < NC - 1 && y < NC - 1 && z < NC - 1;
+          const T   v = buf[(z * NF + y) * NF + x];
+          if (cinner[it])
+            args.dst[cgi[it]] = cold[it] + v; // only this patch touches coarse nodes strictly inside it
+          else
+            atomic_add(&args.dst[cgi[it]], v);
         }
-#pragma unroll
-      for (int it = 0; it < ITC; ++it)
-        old[it] = args.dst[(gi[it] != DEV_INVALID && inner[it]) ? gi[it] : 0];
-#pragma unroll
-      for (int it = 0; it < ITC; ++it)
-        if (gi[it] != DEV_INVALID)
-          {
-            const int idx = tid + it * BLOCK;
-            const int x = idx % NC, y = (idx / NC) % NC, z = idx / (NC * NC);
-            const T   v = buf[(z * NF + y) * NF + x];
-            if (inner[it])
-              args.dst[gi[it]] = old[it] + v; // only this patch touches coarse nodes strictly inside it
-            else
-              atomic_add(&args.dst[gi[it]], v);
-          }
-    }
   }
 
   // ------------------------------------------------------------------------------------------

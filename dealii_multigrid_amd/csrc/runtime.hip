@@ -1670,6 +1670,12 @@ namespace mgamd
     };
     std::vector<std::unique_ptr<LsCopy>> ls_copy;
     size_t                               ls_n_global = 0;
+    const LevelTables                   *ls_active   = nullptr;
+    const LevelTables *
+    outer_tables() const override
+    {
+      return ls_active ? ls_active : ops[nl - 1]->tables.get();
+    }
     void
     setup_local_smoothing(const LevelTables &active) override
     {
@@ -1697,6 +1703,7 @@ namespace mgamd
       if (total != (size_t)active.n_interior + active.n_tail)
         throw std::runtime_error("local smoothing: the levels do not cover every unconstrained DoF of the active mesh exactly once");
       ls_n_global = active.n_dofs;
+      ls_active   = &active;
       if (!defect[nl - 1]->p)
         defect[nl - 1]->alloc(ops[nl - 1]->n_dofs());
     }
@@ -1789,8 +1796,8 @@ namespace mgamd
         {
           if (!amg_like && coarse != "gmg_vcycle")
             throw std::invalid_argument("multigrid: a nested multigrid is the stand-in for the AMG coarse solvers only");
-          if (nested->number_type != (int)sizeof(T) || nested->finest_operator() != ops[0])
-            throw std::invalid_argument("multigrid: the nested multigrid must end on this hierarchy's level 0 (same number type)");
+          if (nested->number_type != (int)sizeof(T) || nested->outer_tables() != ops[0]->tables.get())
+            throw std::invalid_argument("multigrid: the nested multigrid must act on the DoFs of this hierarchy's level 0 (same number type)");
           coarse_type = "gmg_vcycle";
         }
       else if (amg_like)

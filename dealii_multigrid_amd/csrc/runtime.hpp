@@ -247,6 +247,9 @@ namespace mgamd
     int         number_type = MGAMD_F64;
     virtual LevelOperatorBase *
     finest_operator() const = 0;
+    // tables of the vectors vcycle() acts on: the finest level's, or the active mesh's for local smoothing
+    virtual const LevelTables *
+    outer_tables() const = 0;
     // z = V-cycle(r) on raw device pointers of the LEVEL number type (nested use)
     virtual void
     vcycle_level_raw(void *z, const void *r) = 0;

@@ -5,7 +5,7 @@
 //
 //   ./multigrid_throughput input_0000.json [input_0001.json ...]
 //
-// Implemented `Type`s: HMG-global, PMG, HPMG (global coarsening) and HMG-local (local smoothing).  HPMG-local/AMG/AMGPETSc
+// Implemented `Type`s: HMG-global, PMG, HPMG (global coarsening), HMG-local and HPMG-local (local smoothing).  AMG/AMGPETSc
 // raise "not implemented" exactly like the reference's AssertThrow(false, ExcNotImplemented()) for unknown strings.
 #include "../csrc/mgamd.hpp"
 
@@ -303,6 +303,13 @@ run(const Context &ctx, const RunParameters &params, ConvergenceTable &table)
           degrees.push_back(pseq[i]);
         }
     }
+  else if (params.type == "HPMG-local")
+    {
+      // ref:multigrid_throughput.cc:1685-1695,1846-1860: p-multigrid on the active mesh; its coarse problem (lowest degree) is
+      // handed to one local-smoothing V-cycle, built below
+      degrees = create_polynomial_coarsening_sequence(params.fe_degree_fine);
+      triangulations.assign(degrees.size(), tria);
+    }
   else if (params.type == "HMG-local")
     {
       // solve_with_local_smoothing (ref:multigrid_throughput.cc:1670-1873): the levels are the refinement levels of the mesh
@@ -314,13 +321,47 @@ run(const Context &ctx, const RunParameters &params, ConvergenceTable &table)
     throw std::runtime_error("Type '" + params.type + "': not implemented");
   const bool local_smoothing = params.type == "HMG-local";
 
+  const bool hp_local        = params.type == "HPMG-local";
+  PreconditionChebyshev::AdditionalData sd;
+  sd.smoothing_range     = params.mg_data.smoother.smoothing_range;
+  sd.degree              = params.mg_data.smoother.degree;
+  sd.eig_cg_n_iterations = params.mg_data.smoother.eig_cg_n_iterations;
+  // HPMG-local: the local-smoothing hierarchy of the lowest degree (the coarse solver of the p-levels)
+  std::vector<DoFHandler>            ls_dof_handlers;
+  std::vector<Operator>              ls_operators;
+  std::vector<MGTwoLevelTransfer>    ls_transfers;
+  std::vector<PreconditionChebyshev> ls_smoothers;
+  std::unique_ptr<DoFHandler>        ls_active;
+  std::unique_ptr<PreconditionMG>    ls_mg;
+  if (hp_local)
+    {
+      const unsigned nls = tria->n_global_levels();
+      ls_operators.resize(nls);
+      ls_transfers.resize(nls);
+      ls_smoothers.resize(nls);
+      for (unsigned l = 0; l < nls; ++l)
+        ls_dof_handlers.emplace_back(tria->level_mesh(l), degrees.front(), -1, true);
+      ls_active = std::make_unique<DoFHandler>(tria, degrees.front());
+      for (unsigned l = 0; l < nls; ++l)
+        ls_operators[l].reinit(ctx, ls_dof_handlers[l], level_number_type);
+      for (unsigned l = 1; l < nls; ++l)
+        ls_transfers[l].reinit(ls_operators[l], ls_operators[l - 1]);
+      for (unsigned l = 0; l < nls; ++l)
+        ls_smoothers[l].initialize(ls_operators[l], sd);
+      ls_mg = std::make_unique<PreconditionMG>(ctx, ls_operators, ls_transfers, ls_smoothers, params.mg_data.coarse_solver.type, nullptr, 1,
+                                               ls_active.get());
+    }
+
   const unsigned                  n_levels = degrees.size();
   std::vector<DoFHandler>         dof_handlers;
   std::vector<Operator>           operators(n_levels);
   std::vector<MGTwoLevelTransfer> transfers(n_levels);
   std::vector<PreconditionChebyshev> smoothers(n_levels);
   for (unsigned l = 0; l < n_levels; ++l)
-    dof_handlers.emplace_back(triangulations[l], degrees[l], -1, local_smoothing);
+    if (hp_local && l == 0)
+      dof_handlers.push_back(*ls_active); // the SAME DoFs as the local-smoothing cycle acts on
+    else
+      dof_handlers.emplace_back(triangulations[l], degrees[l], -1, local_smoothing);
   std::unique_ptr<DoFHandler> active_dof_handler;
   if (local_smoothing)
     active_dof_handler = std::make_unique<DoFHandler>(tria, params.fe_degree_fine);
@@ -329,17 +370,13 @@ run(const Context &ctx, const RunParameters &params, ConvergenceTable &table)
     operators[l].reinit(ctx, dof_handlers[l], level_number_type);
   for (unsigned l = 1; l < n_levels; ++l)
     transfers[l].reinit(operators[l], operators[l - 1]);
-  PreconditionChebyshev::AdditionalData sd;
-  sd.smoothing_range     = params.mg_data.smoother.smoothing_range;
-  sd.degree              = params.mg_data.smoother.degree;
-  sd.eig_cg_n_iterations = params.mg_data.smoother.eig_cg_n_iterations;
   for (unsigned l = 0; l < n_levels; ++l)
     smoothers[l].initialize(operators[l], sd);
 
   // coarse solver (library policy, include/mgamd.h): the Trilinos/PETSc AMG options are an exact solve on the one-cell coarse
   // level of global coarsening; on a large coarse level (PMG, MinLevel) they are replaced by the geometric stand-in -- V-cycles
   // of the h-multigrid on that level -- and the table says so in its `coarse_solver` column
-  const std::string coarse = params.mg_data.coarse_solver.type;
+  const std::string coarse = hp_local ? std::string("gmg_vcycle") : params.mg_data.coarse_solver.type;
   const bool amg_like      = coarse == "amg" || coarse == "cg_with_amg" || coarse == "amg_petsc";
   std::vector<DoFHandler>            c_dof_handlers;
   std::vector<Operator>              c_operators;
@@ -368,8 +405,8 @@ run(const Context &ctx, const RunParameters &params, ConvergenceTable &table)
                 << "-DoF coarse level: Trilinos/PETSc are not available, using " << params.mg_data.coarse_solver.n_cycles
                 << " V-cycle(s) of the geometric multigrid on that level (gmg_vcycle)" << std::endl;
     }
-  PreconditionMG preconditioner(ctx, operators, transfers, smoothers, coarse, coarse_mg.get(), params.mg_data.coarse_solver.n_cycles,
-                                active_dof_handler.get());
+  PreconditionMG preconditioner(ctx, operators, transfers, smoothers, coarse, hp_local ? ls_mg.get() : coarse_mg.get(),
+                                hp_local ? 1u : params.mg_data.coarse_solver.n_cycles, active_dof_handler.get());
 
   // fine (outer, double) operator, right-hand side (ref:multigrid_throughput.cc:2262-2324)
   Operator op;

@@ -138,3 +138,28 @@ class LocalSmoothing:
 
     def solve(self, reltol=1e-4):
         return o.pcg(self.G.A, self.G.rhs_constant, self.vcycle, reltol)
+
+
+class PolynomialOverLocalSmoothing:
+    """`HPMG-local` (ref:multigrid_throughput.cc:1685-1695,1846-1860): p-multigrid (bisection sequence) on the active mesh whose
+    coarse problem -- the lowest degree -- is handed to ONE local-smoothing V-cycle."""
+
+    def __init__(self, geometry, n_ref_global, degree, smoother_degree=3, numbering_keys_p=None, numbering_keys_levels=None):
+        leaves = o.create_mesh(geometry, n_ref_global)
+        pseq = [degree]
+        while pseq[-1] > 1:
+            pseq.append(max(pseq[-1] // 2, 1))
+        pseq = pseq[::-1]
+        nk = numbering_keys_p or [None] * len(pseq)
+        self.ls = LocalSmoothing(geometry, n_ref_global, pseq[0], smoother_degree, numbering_keys_global=nk[0],
+                                 numbering_keys_levels=numbering_keys_levels)
+        self.levels = [self.ls.G] + [o.Level(leaves, p, nk[i + 1]) for i, p in enumerate(pseq[1:])]
+        self.P = [None] + [o.build_transfer(self.levels[l], self.levels[l - 1]) for l in range(1, len(self.levels))]
+        self.mg = o.Multigrid(self.levels, self.P, smoother_degree, coarse=self.ls.vcycle)
+        self.G = self.levels[-1]
+
+    def vcycle(self, r):
+        return self.mg.vcycle(r)
+
+    def solve(self, reltol=1e-4):
+        return o.pcg(self.G.A, self.G.rhs_constant, self.vcycle, reltol)

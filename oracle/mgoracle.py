@@ -679,6 +679,8 @@ class Multigrid:
 
     def coarse_solve(self, d):
         L0 = self.levels[0]
+        if callable(self.coarse):  # e.g. a local-smoothing V-cycle on level 0's space (HPMG-local)
+            return self.coarse(d)
         if self.coarse == "direct":
             return self.A0.solve(d)
         if self.coarse == "cg":  # ref:multigrid_throughput.cc:911-921

@@ -105,3 +105,26 @@ def test_float_levels_local_smoothing(mgamd, ctx):
     h.fine_operator.rhs(b)
     it, res = mgamd.solve_cg(h.fine_operator, h.mg, x, b, 1e-4)
     assert abs(it - ref.solve(1e-4)[1]) <= 1
+
+
+@pytest.mark.parametrize("geo,L,p", [("quadrant", 3, 4), ("annulus", 5, 2), ("quadrant", 4, 2)])
+def test_hpmg_local(mgamd, ctx, geo, L, p):
+    """`HPMG-local` (ref:multigrid_throughput.cc:1685-1695,1846-1860): p-multigrid on the active mesh over ONE local-smoothing
+    V-cycle at the lowest degree, against the composed oracle"""
+    import ls_oracle
+
+    h = mgamd.Hierarchy(ctx, geo, L, p, "HPMG-local", coarse_solver="amg", max_brick=0)
+    assert h.mg.coarse_solver_used() == "gmg_vcycle" and h.degrees[-1] == p and h.degrees[0] == 1
+    ref = ls_oracle.PolynomialOverLocalSmoothing(geo, L, p, numbering_keys_p=[d.keys() for d in h.dofs],
+                                                 numbering_keys_levels=[d.keys() for d in h.ls["dofs"]])
+    n = ref.G.n
+    r = np.random.default_rng(44).standard_normal(n)
+    r[ref.G.constrained] = 0.0
+    vr, vz = mgamd.Vector(ctx, n).from_host(r), mgamd.Vector(ctx, n)
+    h.mg.vmult(vz, vr)
+    assert rel_err(vz.to_host(), ref.vcycle(r)) < 1e-11
+    xref, itref, hist = ref.solve(1e-4)
+    b, x = h.fine_operator.initialize_dof_vector(), h.fine_operator.initialize_dof_vector()
+    h.fine_operator.rhs(b)
+    it, res = mgamd.solve_cg(h.fine_operator, h.mg, x, b, 1e-4)
+    assert it == itref and rel_err(x.to_host(), xref) < 1e-10

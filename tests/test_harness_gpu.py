@@ -125,7 +125,22 @@ def test_local_smoothing_inputs(tmp_path):
         assert float(r["time_edge_pro"]) > 0 and r["coarse_solver"] == "direct"
 
 
-@pytest.mark.parametrize("key,value,message", [("Type", "HPMG-local", "not implemented"), ("Type", "AMG", "not implemented"),
+def test_hpmg_local_input(tmp_path):
+    """`HPMG-local`: p-levels 1 -> 2 -> 4 on the active mesh over one local-smoothing V-cycle at p = 1"""
+    import ls_oracle
+
+    cfg = dict(json.load(open(os.path.join(GOLDEN, "input_0003.json"))), Type="HPMG-local", MGNumberType="double")
+    f = str(tmp_path / "hpls.json")
+    json.dump(cfg, open(f, "w"))
+    rc, out, err = run_harness(f)
+    assert rc == 0, err
+    header, rows = final_table(out)
+    r = rows[0]
+    assert (int(r["n_dofs"]), int(r["n_levels"]), r["coarse_solver"]) == (9295, 3, "gmg_vcycle")
+    assert int(r["n_iterations"]) == ls_oracle.PolynomialOverLocalSmoothing("quadrant", 3, 4).solve(1e-4)[1]
+
+
+@pytest.mark.parametrize("key,value,message", [("Type", "AMGPETSc", "not implemented"), ("Type", "AMG", "not implemented"),
                                                ("GeometryType", "torus", "not implemented"), ("MGNumberType", "half", "not implemented"),
                                                ("CoarseGridSolverType", "lu", "not implemented")])
 def test_error_behaviour(tmp_path, key, value, message):
