@@ -1028,6 +1028,32 @@ namespace mgamd
     lattice_apply_body<T, P, B, MODE, CONSTR>(args, blockIdx.x, gridDim.x, smem_raw);
   }
 
+  // The plain and the constrained bricks of one size in ONE launch (same lattice, same LDS, same block size): the
+  // constrained group alone is a fraction of a round of workgroups on most levels.  Two inlined copies of the body: the plain
+  // bricks keep the lean instruction stream (the embedding passes are only in the second copy).
+  template <typename T, int P>
+  struct BrickPairArgs
+  {
+    ApplyArgs<T, P> a;             // a.g = the plain group
+    SlotGroupDev    g_constrained; // the constrained bricks of the same size
+    uint32_t        n_wg_plain;
+  };
+  template <typename T, int P, int B, int MODE>
+  __global__ void
+  __launch_bounds__((Geo<P, B>::ABLOCK), (Geo<P, B>::ROUNDS > 1 ? 2 : 1)) lattice_apply_pair_kernel(const BrickPairArgs<T, P> args)
+  {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    if (blockIdx.x < args.n_wg_plain)
+      lattice_apply_body<T, P, B, MODE, false>(args.a, blockIdx.x, args.n_wg_plain, smem_raw);
+    else
+      {
+        ApplyArgs<T, P> a = args.a;
+        a.g               = args.g_constrained;
+        a.stamps          = nullptr;
+        lattice_apply_body<T, P, B, MODE, true>(a, blockIdx.x - args.n_wg_plain, gridDim.x - args.n_wg_plain, smem_raw);
+      }
+  }
+
   // The 2^3 bricks and the single cells of a level in ONE launch (both have 256-thread workgroups and 20-35 KB of LDS):
   // on levels where each of them is a fraction of one round of workgroups, a launch costs a workgroup lifetime whatever
   // it does.  (Merging the 17^3 bricks in as well was measured slower: every workgroup then reserves their 78 KB.)

@@ -657,12 +657,40 @@ namespace mgamd
 
     // launches of one slot group (with its merge partner, if any) on stream st; [begin, end) restricts an unmerged group
     // to a slot range
+    template <int P, int B, int MODE>
+    void
+    launch_pair(hipStream_t st, const ApplyArgs<T, P> &a, GroupDev<T> *g_constrained)
+    {
+      using G = Geo<P, B>;
+      BrickPairArgs<T, P> pa;
+      pa.a             = a;
+      pa.g_constrained = g_constrained->view();
+      pa.n_wg_plain    = (uint32_t)((a.g.n_slots + G::SPW - 1) / G::SPW);
+      const uint32_t n_wg_c = (uint32_t)((g_constrained->n_slots + G::SPW - 1) / G::SPW);
+      const size_t   lds    = (2 * (size_t)G::SPW * G::N3 + 2 * P * P * P + G::SPW) * sizeof(T);
+      auto           kern   = lattice_apply_pair_kernel<T, P, B, MODE>;
+      ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), lds);
+      hipLaunchKernelGGL(kern, pa.n_wg_plain + n_wg_c, G::ABLOCK, lds, st, pa);
+      HIP_CHECK(hipGetLastError());
+    }
+
     template <int P, int MODE>
     void
     launch_group(hipStream_t st, ApplyArgs<T, P> &a, GroupDev<T> *g, GroupDev<T> *partner_cells, GroupDev<T> *partner_clusters,
-                 const T *src, const Epilogue<T> &epi, bool diag, size_t begin, size_t end)
+                 const T *src, const Epilogue<T> &epi, bool diag, size_t begin, size_t end, GroupDev<T> *partner_constrained = nullptr)
     {
       a.g      = (begin == 0 && end == g->n_slots) ? g->view() : g->view(begin, end);
+      if (partner_constrained)
+        {
+          if constexpr (P == 1)
+            {
+              if (g->B == 16)
+                return launch_pair<P, 16, MODE>(st, a, partner_constrained);
+              if (g->B == 8)
+                return launch_pair<P, 8, MODE>(st, a, partner_constrained);
+            }
+          throw std::runtime_error("brick pair launch: size not instantiated");
+        }
       a.stamps = (stamps.p && g->B == prof_B && !g->constrained && MODE == stamp_mode && !diag && begin == 0) ? stamps.p : nullptr;
       if (partner_clusters)
         {
@@ -806,6 +834,15 @@ namespace mgamd
         const double n1 = (double)(g.N - 1), n2 = (double)(g.N - 2);
         ctx->prof_bytes += sizeof(T) * (double)n_slots * (words * n2 * n2 * n2 + 2.0 * (n1 * n1 * n1 - n2 * n2 * n2));
       };
+      // plain + constrained bricks of one size share a launch (p = 1: the only degree with constrained bricks above B = 2)
+      auto constrained_partner = [&](GroupDev<T> *g) -> GroupDev<T> * {
+        if (P != 1 || diag || !merge_small || pipelined || g->constrained || g->B <= 2 || (merged_p1 && g == g8))
+          return nullptr;
+        for (auto &q : groups)
+          if (q->constrained && q->B == g->B && q->n_slots)
+            return q.get();
+        return nullptr;
+      };
       // every group but the pipelined one
       for (size_t gi = 0; gi < groups.size(); ++gi)
         {
@@ -814,9 +851,17 @@ namespace mgamd
             continue;
           if ((merged && g == g1) || (merged_p1 && g == gc))
             continue; // done together with the 2^3 (8^3) bricks
+          if (g->constrained && !diag && merge_small && !pipelined && P == 1)
+            {
+              bool has_plain = false;
+              for (auto &q : groups)
+                has_plain |= !q->constrained && q->B == g->B && q->n_slots && !(merged_p1 && q.get() == g8);
+              if (has_plain)
+                continue; // launched together with the plain bricks of its size
+            }
           const bool prof = !pipelined && prof_begin(*g);
           launch_group<P, MODE>(side, a, g, (merged && g == g2) ? g1 : nullptr, (merged_p1 && g == g8) ? gc : nullptr, src, epi, diag, 0,
-                                g->n_slots);
+                                g->n_slots, constrained_partner(g));
           if (prof)
             prof_end(*g, g->n_slots);
         }
