@@ -28,3 +28,23 @@ for geo, L, p, typ in CASES:
     })
     print(out[-1]["geometry"], L, p, typ, out[-1]["n_iterations"], out[-1]["n_dofs"])
 json.dump(out, open(os.path.join(HERE, "oracle_solve.json"), "w"), indent=1)
+
+# local smoothing (oracle/ls_oracle.py): HMG-local and HPMG-local
+import ls_oracle as lo
+
+LS_CASES = [("quadrant", 3, 1, "HMG-local"), ("quadrant", 4, 2, "HMG-local"), ("annulus", 5, 1, "HMG-local"), ("quadrant", 3, 4, "HPMG-local")]
+ls_out = []
+for geo, L, p, typ in LS_CASES:
+    s = lo.LocalSmoothing(geo, L, p) if typ == "HMG-local" else lo.PolynomialOverLocalSmoothing(geo, L, p)
+    x, it, hist = s.solve(1e-4)
+    ls = s if typ == "HMG-local" else s.ls
+    ls_out.append({
+        "geometry": geo, "n_ref_global": L, "degree": p, "type": typ,
+        "level_n_dofs": [int(v.n) for v in ls.levels], "level_n_edge": [int(v.edge.sum()) for v in ls.levels],
+        "level_n_copied": [int(len(g)) for g, _ in ls.copy],
+        "n_iterations": it, "residual_history": [float(h) for h in hist],
+        "max_eigenvalue_estimates": [float(sm.max_ev) for sm in ls.sm],
+        "solution_l2": float(np.linalg.norm(x)),
+    })
+    print(geo, L, p, typ, it, ls_out[-1]["level_n_dofs"])
+json.dump(ls_out, open(os.path.join(HERE, "oracle_local_smoothing.json"), "w"), indent=1)

@@ -20,7 +20,7 @@ WORKER = textwrap.dedent(
 
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    geo, L, p = "quadrant", 4, 2
+    geo, L, p = sys.argv[2], int(sys.argv[3]), int(sys.argv[4])  # p: one level of a PMG hierarchy lives on the finest mesh too
     trias = m.create_geometric_coarsening_sequence(m.Triangulation(geo, L))
     part = m.Partition(trias, world)
     lvl = len(trias) - 1
@@ -66,11 +66,17 @@ WORKER = textwrap.dedent(
 )
 
 
-def test_halo_exchange_over_gloo_world_size_2(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize("geo,L,p,port", [("quadrant", 4, 2, 29517), ("annulus", 5, 4, 29518), ("annulus", 5, 1, 29519)])
+def test_halo_exchange_over_gloo_world_size_2(tmp_path, geo, L, p, port):
+    """octant p=2 (HMG-global finest level) and the p=4 / p=1 levels of the PMG annulus hierarchy (BASELINE configs[4]): all
+    levels of a PMG hierarchy share the finest mesh's partition"""
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29517", str(script), ROOT], capture_output=True, text=True, env=env, timeout=600)
+                          "--master-port", str(port), str(script), ROOT, geo, str(L), str(p)], capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "GLOO_OK 2" in out.stdout
