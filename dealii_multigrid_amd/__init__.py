@@ -113,7 +113,7 @@ class Triangulation:
         return lev, i, j, k, mask
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and _lib is not None:
             _lib.mgamd_tria_destroy(self._h)
             self._h = None
 
@@ -159,7 +159,7 @@ class Partition:
         return o
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and _lib is not None:
             _lib.mgamd_partition_destroy(self._h)
             self._h = None
 
@@ -237,7 +237,7 @@ class DoFs:
         return plan
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and _lib is not None:
             _lib.mgamd_dofs_destroy(self._h)
             self._h = None
 
@@ -293,7 +293,7 @@ class Context:
         return ms.value, n.value, b.value
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and _lib is not None:
             _lib.mgamd_ctx_destroy(self._h)
             self._h = None
 
@@ -312,7 +312,7 @@ class SimGroup:
         return Communicator(h, self.n_ranks, rank, self)
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and _lib is not None:
             _lib.mgamd_sim_group_destroy(self._h)
             self._h = None
 
@@ -339,7 +339,7 @@ class Communicator:
         return r.value
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and _lib is not None:
             _lib.mgamd_comm_destroy(self._h)
             self._h = None
 
@@ -389,7 +389,7 @@ class Vector:
         return r.value
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and _lib is not None:
             _lib.mgamd_vec_destroy(self._h)
             self._h = None
 
@@ -444,7 +444,7 @@ class Operator:
         _chk(_lib.mgamd_level_op_distribute(self._h, kind, x._h))
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and _lib is not None:
             _lib.mgamd_level_op_destroy(self._h)
             self._h = None
 
@@ -467,7 +467,7 @@ class PreconditionChebyshev:
         return lo.value, hi.value
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and _lib is not None:
             _lib.mgamd_cheb_destroy(self._h)
             self._h = None
 
@@ -485,7 +485,7 @@ class MGTwoLevelTransfer:
         _chk(_lib.mgamd_transfer2_restrict_and_add(self._h, dst_coarse._h, src_fine._h))
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and _lib is not None:
             _lib.mgamd_transfer2_destroy(self._h)
             self._h = None
 
@@ -558,7 +558,7 @@ class PreconditionMG:
         return ms.value
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and _lib is not None:
             _lib.mgamd_mg_destroy(self._h)
             self._h = None
 
