@@ -75,6 +75,7 @@ class DofsInfo(C.Structure):
         ("n_peers", C.c_uint32),
         ("n_halo_send", C.c_uint32),
         ("n_edge", C.c_uint32),
+        ("group_halo_slots", C.c_uint64 * 8),
     ]
 
 

@@ -150,6 +150,7 @@ mgamd_dofs_info(const mgamd_dofs *d, mgamd_dofs_info_t *info)
     {
       info->group_B[g]     = L.groups[g].B;
       info->group_slots[g] = L.groups[g].n_slots();
+      info->group_halo_slots[g] = L.groups[g].n_halo_slots;
     }
   MGAMD_CATCH
 }

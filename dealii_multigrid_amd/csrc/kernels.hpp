@@ -1111,6 +1111,7 @@ namespace mgamd
     const T *b, *dinv;
     T        c0;
     int      from_b;
+    uint32_t cluster_offset; // first cluster of this launch (the halo / interior split of sharded levels)
   };
 
   template <typename T, bool TRANSPOSE>
@@ -1179,7 +1180,7 @@ namespace mgamd
     T *Acc = U + a.c.max_uniq;
 
     const int      tid  = threadIdx.x;
-    const uint32_t cl   = xcd_contiguous(block, nblocks);
+    const uint32_t cl   = a.cluster_offset + xcd_contiguous(block, nblocks);
     const uint32_t slot = cl * CLUSTER_CELLS + tid;
     const bool     act  = slot < a.c.n_slots;
     const uint32_t p0   = a.c.uniq_ptr[cl];

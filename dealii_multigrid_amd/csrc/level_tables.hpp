@@ -104,6 +104,9 @@ namespace mgamd
     std::vector<double>   h;             // per slot: cell edge length
     std::vector<uint32_t> first_cell;    // per slot: index of its first cell in Tria::cells
     std::vector<uint16_t> shell_pos;     // n_shell: lattice index (z*N+y)*N+x of each shell entry
+    // sharded levels: the first n_halo_slots slots of the group touch DoFs shared with other ranks; the halo exchange of an
+    // operator application only needs them, so the others run underneath it (runtime.hip, apply_P)
+    uint32_t n_halo_slots = 0;
     // p = 1, B > 2: the constrained bricks form a group of their own (their kernel carries the embedding passes; the
     // unconstrained bricks keep the lean kernel).  Families (B = 2) share the group of the 2^3 bricks.
     bool constrained_group = false;
@@ -1159,6 +1162,56 @@ namespace mgamd
       for (SlotGroup &g : groups)
         for (uint32_t &v : g.shell_idx)
           v = (v == INVALID_DOF || (v >> CLS_SHIFT) == 1) ? INVALID_DOF : final_index(v);
+      // ---- 4. sharded level: slots that touch shared DoFs first (stable), per group
+      if (shared && !shared->empty())
+        {
+          std::vector<uint8_t> is_shared(n_dofs, 0);
+          for (size_t t = 0; t < key_list.size(); ++t)
+            if (shared->find(key_list[t]) != shared->end())
+              is_shared[key_index[t]] = 1;
+          for (size_t gi = 0; gi < groups.size(); ++gi)
+            {
+              SlotGroup   &g  = groups[gi];
+              const size_t ns = g.n_slots();
+              if (!ns)
+                continue;
+              std::vector<uint32_t> perm; // new position -> old slot
+              std::vector<uint8_t>  halo(ns, 0);
+              for (size_t sl = 0; sl < ns; ++sl)
+                for (int t = 0; t < g.n_shell && !halo[sl]; ++t)
+                  {
+                    const uint32_t v = g.shell_idx[sl * g.n_shell + t];
+                    if (v != INVALID_DOF && is_shared[v])
+                      halo[sl] = 1;
+                  }
+              for (size_t sl = 0; sl < ns; ++sl)
+                if (halo[sl])
+                  perm.push_back((uint32_t)sl);
+              g.n_halo_slots = (uint32_t)perm.size();
+              for (size_t sl = 0; sl < ns; ++sl)
+                if (!halo[sl])
+                  perm.push_back((uint32_t)sl);
+              auto permute = [&](auto &v, size_t width) {
+                if (v.empty())
+                  return;
+                auto old = v;
+                for (size_t n2 = 0; n2 < ns; ++n2)
+                  std::copy(old.begin() + perm[n2] * width, old.begin() + (perm[n2] + 1) * width, v.begin() + n2 * width);
+              };
+              permute(g.interior_base, 1);
+              permute(g.shell_idx, (size_t)g.n_shell);
+              permute(g.mask, 1);
+              permute(g.fmask, 1);
+              permute(g.h, 1);
+              permute(g.first_cell, 1);
+              std::vector<uint32_t> new_of_old(ns);
+              for (size_t n2 = 0; n2 < ns; ++n2)
+                new_of_old[perm[n2]] = (uint32_t)n2;
+              for (size_t ci = 0; ci < nc; ++ci)
+                if (cell_group[ci] == gi)
+                  cell_slot[ci] = new_of_old[cell_slot[ci]];
+            }
+        }
     }
   };
 } // namespace mgamd

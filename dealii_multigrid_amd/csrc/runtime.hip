@@ -381,6 +381,7 @@ namespace mgamd
   {
     int            B = 1, N = 2;
     bool           constrained = false; // the group of constrained bricks larger than a family
+    size_t         n_halo      = 0;     // sharded levels: the first n_halo slots touch DoFs shared with other ranks
     size_t         n_slots = 0;
     DBuf<uint32_t> interior_base, shell_idx;
     DBuf<uint16_t> mask, shell_pos;
@@ -460,6 +461,7 @@ namespace mgamd
     DBuf<unsigned long long>                  stamps;     // debug: MGAMD_STAMPS=<mode>, 8 stamps per workgroup of the largest group
     int                                       stamp_mode = -1;
     bool                                      merge_small = true; // MGAMD_NO_MERGE_SMALL=1: separate launches (development A/B)
+    bool                                      halo_overlap = true; // MGAMD_NO_HALO_OVERLAP=1: exchange after all slots, on the main queue
 
     // sharded runs: device image of the halo plan
     struct HaloDev
@@ -499,6 +501,7 @@ namespace mgamd
           d->B           = g.B;
           d->N           = g.N;
           d->constrained = g.constrained_group;
+          d->n_halo      = g.n_halo_slots;
           d->n_slots = g.n_slots();
           if (d->n_slots)
             {
@@ -523,6 +526,7 @@ namespace mgamd
       if (const char *e = getenv("MGAMD_ABLATE"))
         ablate = (uint32_t)atoi(e);
       merge_small = getenv("MGAMD_NO_MERGE_SMALL") == nullptr;
+      halo_overlap = getenv("MGAMD_NO_HALO_OVERLAP") == nullptr;
       if (const char *e = getenv("MGAMD_STAMPS"))
         {
           stamp_mode = atoi(e);
@@ -539,17 +543,19 @@ namespace mgamd
 
     // tail[t] <- sum over the sharing ranks (ascending rank order) of their partial tail[t]
     void
-    exchange_add_raw(T *tail)
+    exchange_add_raw(T *tail, hipStream_t st = nullptr)
     {
       if (!halo)
         return;
+      if (!st)
+        st = ctx->stream;
       const uint32_t ns = (uint32_t)halo_plan->pack_idx.size();
       if (ns)
-        hipLaunchKernelGGL(halo_pack_kernel<T>, grid_for(ns), 256, 0, ctx->stream, halo->send.p, tail, halo->pack_idx.p, ns);
-      comm->exchange(halo->send.p, halo->recv.p, halo_plan->peers, halo_plan->peer_offset, sizeof(T), ctx->stream);
+        hipLaunchKernelGGL(halo_pack_kernel<T>, grid_for(ns), 256, 0, st, halo->send.p, tail, halo->pack_idx.p, ns);
+      comm->exchange(halo->send.p, halo->recv.p, halo_plan->peers, halo_plan->peer_offset, sizeof(T), st);
       const uint32_t nsh = (uint32_t)halo_plan->sh_tail.size();
       if (nsh)
-        hipLaunchKernelGGL(halo_combine_kernel<T>, grid_for(nsh), 256, 0, ctx->stream, tail, halo->recv.p, halo->sh_tail.p, halo->sh_ptr.p,
+        hipLaunchKernelGGL(halo_combine_kernel<T>, grid_for(nsh), 256, 0, st, tail, halo->recv.p, halo->sh_tail.p, halo->sh_ptr.p,
                            halo->sh_src.p, nsh);
       HIP_CHECK(hipGetLastError());
     }
@@ -634,11 +640,13 @@ namespace mgamd
       a.dinv       = epi.dinv;
       a.c0         = epi.c0;
       a.from_b     = first ? 1 : 0;
+      a.cluster_offset = 0;
       return a;
     }
 
     void
-    launch_clusters(hipStream_t st, const GroupDev<T> &g, const T *src, const Epilogue<T> &epi, bool first)
+    launch_clusters(hipStream_t st, const GroupDev<T> &g, const T *src, const Epilogue<T> &epi, bool first, uint32_t cluster_begin = 0,
+                    uint32_t cluster_end = 0xFFFFFFFFu)
     {
       ClusterArgs<T> a;
       a.c          = g.cluster_view();
@@ -650,7 +658,13 @@ namespace mgamd
       a.dinv       = epi.dinv;
       a.c0         = epi.c0;
       a.from_b     = first ? 1 : 0;
-      const uint32_t grid = (uint32_t)((g.n_slots + CLUSTER_CELLS - 1) / CLUSTER_CELLS);
+      a.cluster_offset = 0;
+      const uint32_t n_cl = (uint32_t)((g.n_slots + CLUSTER_CELLS - 1) / CLUSTER_CELLS);
+      cluster_end         = std::min(cluster_end, n_cl);
+      if (cluster_begin >= cluster_end)
+        return;
+      a.cluster_offset    = cluster_begin;
+      const uint32_t grid = cluster_end - cluster_begin;
       hipLaunchKernelGGL(cell_cluster_apply_kernel<T>, grid, CLUSTER_CELLS, 2 * (size_t)std::max<uint32_t>(g.max_uniq, 1) * sizeof(T), st, a);
       HIP_CHECK(hipGetLastError());
     }
@@ -805,6 +819,45 @@ namespace mgamd
           }
       const bool merged_p1 = g8 && gc;
 
+      // Sharded level: the slots that touch shared DoFs first (LevelTables puts them at the front of every group), then
+      // the halo exchange on the side queue UNDERNEATH the remaining slots (ref: MatrixFree::cell_loop overlaps its ghost
+      // exchange with the interior cell ranges, ref:include/operator.h:166-167).  Plain launches per group and range.
+      if (halo && !diag && halo_overlap)
+        {
+          auto halo_end = [&](const GroupDev<T> &g) -> size_t {
+            size_t nh = g.n_halo;
+            if (P == 1 && g.has_clusters()) // the cluster kernel works on whole 256-cell clusters
+              nh = std::min(g.n_slots, (nh + CLUSTER_CELLS - 1) / CLUSTER_CELLS * CLUSTER_CELLS);
+            return nh;
+          };
+          auto launch_range = [&](GroupDev<T> *g, size_t begin, size_t end) {
+            if (begin >= end)
+              return;
+            if (P == 1 && g->has_clusters())
+              launch_clusters(ctx->stream, *g, src, epi, MODE == MODE_CHEB_FIRST, (uint32_t)(begin / CLUSTER_CELLS),
+                              (uint32_t)((end + CLUSTER_CELLS - 1) / CLUSTER_CELLS));
+            else
+              {
+                a.g = g->view(begin, end);
+                dispatch_B<T, P, MODE>(ctx, ctx->stream, g->B, g->constrained, a, diag);
+              }
+          };
+          size_t n_interior_slots = 0;
+          for (auto &g : groups)
+            n_interior_slots += g->n_slots - halo_end(*g);
+          if (n_interior_slots > 0)
+            {
+              for (auto &g : groups)
+                launch_range(g.get(), 0, halo_end(*g));
+              ctx->order_after(ctx->side, ctx->stream); // the side queue waits for the halo slots only
+              for (auto &g : groups)
+                launch_range(g.get(), halo_end(*g), g->n_slots);
+              exchange_add_raw(tail_acc.p, ctx->side); // (enqueued after the interior slots: the simulator's exchange blocks the host)
+              ctx->order_after(ctx->stream, ctx->side);
+              launch_tail<MODE>(ctx->stream, 0, tail_end, true, epi, diag);
+              return;
+            }
+        }
       const int         pg        = tables->pipeline_group;
       const bool        pipelined = !diag && pg >= 0 && !tables->chunk_slot_end.empty() && groups[pg]->n_slots > 0;
       const hipStream_t main = ctx->stream, side = pipelined ? ctx->side : ctx->stream;

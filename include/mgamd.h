@@ -84,6 +84,9 @@ typedef struct
   /* local-smoothing levels (mgamd_dofs_create_level): refinement-edge DoFs, numbered between the tail and the Dirichlet
    * DoFs: [ I | T | E | D | H ] */
   uint32_t n_edge;
+  /* sharded levels: the first group_halo_slots[g] slots of group g touch DoFs shared with other ranks (the halo exchange of
+   * an operator application runs underneath the remaining slots) */
+  uint64_t group_halo_slots[8];
 } mgamd_dofs_info_t;
 
 /* DoFHandler::distribute_dofs(FE_Q(degree)) + zero Dirichlet on boundary id 0 + hanging-node

@@ -161,3 +161,34 @@ def test_partition_statistics_match_a_python_restatement(mgamd):
     assert 0.5 < st["horizontal_eff"] < 1.0 and st["mem_total"] > 0
     one = mgamd.Partition(trias, 1, 2.0, 0).statistics()
     assert one["workload_eff"] == 1.0 and one["vertical_eff"] == 1.0 and one["horizontal_eff"] == 1.0
+
+
+@pytest.mark.parametrize("geo,L,p,n_ranks", [("quadrant", 5, 2, 3), ("quadrant", 5, 4, 2), ("annulus", 6, 1, 4), ("hypercube", 5, 2, 2)])
+def test_halo_slots_come_first(mgamd, geo, L, p, n_ranks):
+    """sharded level: in every slot group the slots that touch DoFs shared with other ranks are at the front
+    (group_halo_slots), so that the halo exchange of an operator application can run underneath the remaining slots"""
+    trias = mgamd.create_geometric_coarsening_sequence(mgamd.Triangulation(geo, L))
+    part = mgamd.Partition(trias, n_ranks, 2.0, 0)
+    lvl = len(trias) - 1
+    owner = part.owner(lvl)
+    for rank in range(n_ranks):
+        d = mgamd.DoFs(trias[lvl], p, 0, part, lvl, rank)
+        plan = d.halo_plan()
+        info = d.info
+        shared = np.zeros(d.n_dofs, bool)
+        shared[info.n_interior + plan["sh_tail"]] = True
+        cg, cs = d.cell_slots()
+        cd = d.cell_dofs()
+        touches = {}  # (group, slot) -> touches a shared tail DoF
+        for ci in np.nonzero(owner == rank)[0]:
+            idx = cd[ci]
+            idx = idx[idx != mgamd.INVALID_DOF]
+            key = (int(cg[ci]), int(cs[ci]))
+            touches[key] = touches.get(key, False) or bool(shared[idx].any())
+        n_front = 0
+        for (g, sl), t in touches.items():
+            nh = info.group_halo_slots[g]
+            if t:
+                assert sl < nh, (g, sl, nh)  # every slot touching a shared tail DoF is in the halo part
+            n_front += sl < nh
+        assert 0 < n_front < len(touches)  # and there is an interior part to overlap with
