@@ -306,6 +306,95 @@ namespace mgamd
       }
   }
 
+  // ---- one lattice line, in place, CELL BY CELL (streamed): the inputs of a cell are read, its products formed, its first
+  // P nodes stored (the first one with the carry of the previous cell), its last node carried on.  Same arithmetic as
+  // line_MK / line_M_KM / line_KM on whole lines, but ~35 instead of ~70 doubles in registers per thread: what lets the
+  // persistent kernel keep its epilogue operands and the next slot's tables in flight across the sweeps.
+  // KIND 0: A <- M a, Bb <- K a;  1: A <- M a, Bb <- K a + M b;  2: A <- scale (K a + M b)     (a from A, b from Bb)
+  template <typename T, int P, int B, int KIND>
+  __device__ __forceinline__ void
+  line_stream(const Mats<P> &m, T *__restrict__ A, T *__restrict__ Bb, const int stride, const T scale)
+  {
+    constexpr int n = P + 1;
+    T             a[n], b[n], c1 = T(0), c2 = T(0);
+    a[0] = A[0];
+    b[0] = KIND == 0 ? T(0) : Bb[0];
+#pragma unroll
+    for (int c = 0; c < B; ++c)
+      {
+#pragma unroll
+        for (int j = 1; j < n; ++j)
+          {
+            a[j] = A[(c * P + j) * stride];
+            if (KIND != 0)
+              b[j] = Bb[(c * P + j) * stride];
+          }
+        T o1[n], o2[n];
+#pragma unroll
+        for (int i = 0; i < n; ++i)
+          o1[i] = o2[i] = T(0);
+        if constexpr (P < 4)
+          {
+#pragma unroll
+            for (int i = 0; i < n; ++i)
+#pragma unroll
+              for (int j = 0; j < n; ++j)
+                {
+                  if (KIND != 2)
+                    o1[i] += T(m.M[i * n + j]) * a[j];
+                  o2[i] += T(m.K[i * n + j]) * a[j];
+                  if (KIND != 0)
+                    o2[i] += T(m.M[i * n + j]) * b[j];
+                }
+          }
+        else
+          {
+            EvenOdd<T, P> xa, xb, y;
+            xa.split(a);
+            if (KIND != 0)
+              xb.split(b);
+            if (KIND != 2)
+              {
+                y.template apply<false>(m.Me, m.Mo, xa);
+                y.add_to(o1);
+              }
+            y.template apply<false>(m.Ke, m.Ko, xa);
+            if (KIND != 0)
+              y.template apply<true>(m.Me, m.Mo, xb);
+            y.add_to(o2);
+          }
+        o1[0] += c1;
+        o2[0] += c2;
+#pragma unroll
+        for (int j = 0; j < P; ++j)
+          {
+            if (KIND == 0)
+              {
+                A[(c * P + j) * stride]  = o1[j];
+                Bb[(c * P + j) * stride] = o2[j];
+              }
+            else if (KIND == 1)
+              {
+                A[(c * P + j) * stride]  = o1[j];
+                Bb[(c * P + j) * stride] = o2[j];
+              }
+            else
+              A[(c * P + j) * stride] = scale * o2[j];
+          }
+        c1   = o1[P];
+        c2   = o2[P];
+        a[0] = a[P];
+        b[0] = b[P];
+      }
+    if (KIND != 2)
+      {
+        A[P * B * stride]  = c1;
+        Bb[P * B * stride] = c2;
+      }
+    else
+      A[P * B * stride] = scale * c2;
+  }
+
   // ---- SEGMENT tasks for the 17-point lattices.  17^2 = 289 lines do not fit one round of 256 threads, and a second round
   // of whole lines runs with 33 of 256 lanes (measured: the sweeps are 5.9 of the 13-16 us a workgroup lives).  The 33
   // left-over lines are cut into 4 segments of 5 nodes (4 s .. 4 s + 4: one cell at p = 4, two at p = 2, four at p = 1):
@@ -368,9 +457,18 @@ namespace mgamd
 
   // The three sweeps.  Line l = tid + r*BLOCK (r < ROUNDS) of the workgroup is (slot sl, u, v) in every sweep.
   // bufA holds the input and receives the result; bufB is scratch.  Ends with a barrier.
-  template <typename T, int P, int B, int BLOCK>
+  struct NoHook
+  {
+    __device__ __forceinline__ void
+    operator()() const
+    {}
+  };
+  // before_x: called between the y and the x sweep (the x sweep holds one line less in registers than the y sweep: the
+  // persistent kernel requests its epilogue operands there)
+  template <typename T, int P, int B, int BLOCK, typename Hook = NoHook, bool STREAMED = false>
   __device__ __forceinline__ void
-  lattice_sweeps(T *__restrict__ bufA, T *__restrict__ bufB, const Mats<P> &m, int tid, int nslots, const double *__restrict__ hslot)
+  lattice_sweeps(T *__restrict__ bufA, T *__restrict__ bufB, const Mats<P> &m, int tid, int nslots, const double *__restrict__ hslot,
+                 const Hook &before_x = Hook())
   {
     using G              = Geo<P, B>;
     constexpr int N      = G::N;
@@ -380,6 +478,7 @@ namespace mgamd
     constexpr bool SEGMENTS = N == 17 && G::SPW == 1 && TOT > BLOCK && 4 * (TOT - BLOCK) <= BLOCK && (4 % P == 0);
     constexpr int  ROUNDS   = SEGMENTS ? 1 : (TOT + BLOCK - 1) / BLOCK;
     constexpr int  NSEG     = SEGMENTS ? 4 * (TOT - BLOCK) : 0;
+    constexpr bool STREAM   = STREAMED; // whole lines cell by cell (line_stream)
     // segment task of this thread: line BLOCK + tid / 4, segment tid % 4
     const int  sg_l = BLOCK + (tid >> 2), sg_s = tid & 3, sg_u = sg_l % N, sg_v = sg_l / N;
     const bool sg   = SEGMENTS && tid < NSEG;
@@ -392,15 +491,20 @@ namespace mgamd
         if (l < TOT && sl < nslots)
           {
             const int base = sl * N3 + v * N + u;
-#pragma unroll
-            for (int i = 0; i < N; ++i)
-              r0[i] = bufA[base + i * N * N];
-            line_MK<T, P, B>(m, r0, r1, r2);
-#pragma unroll
-            for (int i = 0; i < N; ++i)
+            if constexpr (STREAM)
+              line_stream<T, P, B, 0>(m, bufA + base, bufB + base, N * N, T(1));
+            else
               {
-                bufA[base + i * N * N] = r1[i];
-                bufB[base + i * N * N] = r2[i];
+#pragma unroll
+                for (int i = 0; i < N; ++i)
+                  r0[i] = bufA[base + i * N * N];
+                line_MK<T, P, B>(m, r0, r1, r2);
+#pragma unroll
+                for (int i = 0; i < N; ++i)
+                  {
+                    bufA[base + i * N * N] = r1[i];
+                    bufB[base + i * N * N] = r2[i];
+                  }
               }
           }
       }
@@ -431,19 +535,24 @@ namespace mgamd
         if (l < TOT && sl < nslots)
           {
             const int base = sl * N3 + v * N * N + u;
-#pragma unroll
-            for (int i = 0; i < N; ++i)
-              r0[i] = bufA[base + i * N];
-            T rb[N];
-#pragma unroll
-            for (int i = 0; i < N; ++i)
-              rb[i] = bufB[base + i * N];
-            line_M_KM<T, P, B>(m, r0, rb, r1, r2);
-#pragma unroll
-            for (int i = 0; i < N; ++i)
+            if constexpr (STREAM)
+              line_stream<T, P, B, 1>(m, bufA + base, bufB + base, N, T(1));
+            else
               {
-                bufA[base + i * N] = r1[i];
-                bufB[base + i * N] = r2[i];
+#pragma unroll
+                for (int i = 0; i < N; ++i)
+                  r0[i] = bufA[base + i * N];
+                T rb[N];
+#pragma unroll
+                for (int i = 0; i < N; ++i)
+                  rb[i] = bufB[base + i * N];
+                line_M_KM<T, P, B>(m, r0, rb, r1, r2);
+#pragma unroll
+                for (int i = 0; i < N; ++i)
+                  {
+                    bufA[base + i * N] = r1[i];
+                    bufB[base + i * N] = r2[i];
+                  }
               }
           }
       }
@@ -469,6 +578,7 @@ namespace mgamd
               }
         }
     __syncthreads();
+    before_x();
     // x sweep: line = (y=u, z=v): out = h (Kx c + Mx g)
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r)
@@ -478,16 +588,21 @@ namespace mgamd
           {
             const T   h    = T(hslot[sl]);
             const int base = sl * N3 + (v * N + u) * N;
+            if constexpr (STREAM)
+              line_stream<T, P, B, 2>(m, bufA + base, bufB + base, 1, h);
+            else
+              {
 #pragma unroll
-            for (int i = 0; i < N; ++i)
-              r0[i] = bufA[base + i];
+                for (int i = 0; i < N; ++i)
+                  r0[i] = bufA[base + i];
 #pragma unroll
-            for (int i = 0; i < N; ++i)
-              r1[i] = bufB[base + i];
-            line_KM<T, P, B>(m, r0, r1, r2);
+                for (int i = 0; i < N; ++i)
+                  r1[i] = bufB[base + i];
+                line_KM<T, P, B>(m, r0, r1, r2);
 #pragma unroll
-            for (int i = 0; i < N; ++i)
-              bufA[base + i] = h * r2[i];
+                for (int i = 0; i < N; ++i)
+                  bufA[base + i] = h * r2[i];
+              }
           }
       }
     if constexpr (SEGMENTS)
@@ -765,7 +880,7 @@ namespace mgamd
     // per slot.  One vector word less per interior DoF and Chebyshev pass.
     // Used at P = 1 (one node type: the look-up is a broadcast, -11 % on the 17^3 kernel); at P = 4 the 64-entry look-up
     // per entry pushes the 17^3 kernel over its 256 VGPRs (measured 1113 -> 1829 us), so D^-1 is read from memory there.
-    constexpr bool CLOSED_DINV = P == 1;
+    constexpr bool CLOSED_DINV = P == 1 || (P == 4 && B == 4);
     T *dtab = bufB + G::SPW * G::N3; // [P^3] s, [P^3] 1/s, [SPW] 1/h
     if (CLOSED_DINV && is_cheb(MODE) && G::N_INT > 0)
       {
@@ -1017,6 +1132,304 @@ namespace mgamd
       }
 #endif
   }
+
+  // K1p: the same operator application with PERSISTENT workgroups (one-slot-per-workgroup lattices: N^2 >= 256 lines).
+  // Measured on MI355X (tools/stamps.py, octant p=4 L=8, 5-word Chebyshev pass): a workgroup of lattice_apply_body lives
+  // 16.2 us per brick, 7.8 us of them in the gather (two DEPENDENT global round trips: slot tables -> values, at the
+  // loaded-memory latency), 4.4 us in the sweeps, 3.7 us in epilogue + atomics; with 2 workgroups per CU (LDS) nothing hides
+  // the gather, and removing 17 % of the kernel's HBM bytes (closed-form D^-1) changed nothing: the pass is bound by that
+  // latency chain, not by bytes.  Here workgroup w walks the slots v = w, w + stride, ... (stride = number of resident
+  // workgroups, a multiple of 8: xcd_contiguous keeps every workgroup inside the Morton range of its XCD) and runs a
+  // software pipeline over them:
+  //     top      values of slot v (requested one iteration earlier) -> LDS;  slot tables of v' = v + stride requested
+  //     sweeps   (epilogue operands of v in flight, as before)
+  //     after    the VALUES of v' are requested (the registers of the sweeps are free again), then epilogue + atomics of v
+  // so both round trips of the next gather overlap with work of the current slot.  D^-1 of interior DoFs always in closed
+  // form (see lattice_apply_body): that is what frees the registers for the second set of gathered values.
+  template <typename T, int P, int B, int MODE, bool CONSTR = false>
+  __device__ __forceinline__ void
+  lattice_apply_persistent_body(const ApplyArgs<T, P> &args, const uint32_t w, const uint32_t stride, unsigned char *smem_raw)
+  {
+    using G  = Geo<P, B>;
+    using IM = InteriorMap<P, B>;
+    static_assert(G::SPW == 1 && G::N_INT > 0, "persistent workgroups: one slot per workgroup");
+    T *bufA = reinterpret_cast<T *>(smem_raw);
+    T *bufB = bufA + G::N3;
+    T *dtab = bufB + G::N3; // [P^3] s = d/h, [P^3] 1/s
+
+    constexpr int BLOCK = G::ABLOCK;
+    constexpr int ITER  = IM::ITER;
+    constexpr int ITERS = (G::N_SHELL + BLOCK - 1) / BLOCK;
+    constexpr int P3    = P * P * P;
+
+    const int      tid = threadIdx.x;
+    const uint32_t n   = args.g.n_slots;
+    if (w >= n)
+      return;
+
+    if (is_cheb(MODE))
+      {
+        for (int t = tid; t < P3; t += BLOCK)
+          {
+            const int tt[3] = {t % P, (t / P) % P, t / (P * P)};
+            T         m[3], k[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+              {
+                T dm = T(0), dk = T(0);
+                if (tt[d] == 0)
+                  { // last node of one cell + first node of the next
+                    dm = T(args.m.M[P * (P + 1) + P]) + T(args.m.M[0]);
+                    dk = T(args.m.K[P * (P + 1) + P]) + T(args.m.K[0]);
+                  }
+#pragma unroll
+                for (int q = 1; q < P; ++q)
+                  if (q == tt[d])
+                    {
+                      dm = T(args.m.M[q * (P + 1) + q]);
+                      dk = T(args.m.K[q * (P + 1) + q]);
+                    }
+                m[d] = dm;
+                k[d] = dk;
+              }
+            const T sv   = k[0] * m[1] * m[2] + m[0] * k[1] * m[2] + m[0] * m[1] * k[2];
+            dtab[t]      = sv;
+            dtab[P3 + t] = T(1) / sv;
+          }
+      }
+    // interior entry `it` of this thread is entry i = tid + it BLOCK of the slot (lattice order, NI^3 entries).  Its lattice
+    // coordinates are NOT held in registers (14 VGPRs that the pipeline needs): every phase walks them from (x0, y0, z0) of
+    // entry `tid` by the constant step BLOCK = DZ NI^2 + DY NI + DX with two carries (InteriorWalk).
+    constexpr int NI = IM::NI_;
+    struct InteriorWalk
+    {
+      int x, y, z; // 1-based lattice coordinates of the current entry
+      __device__ __forceinline__ int
+      pos() const
+      {
+        return (z * G::N + y) * G::N + x;
+      }
+      __device__ __forceinline__ int
+      type() const
+      {
+        return (x % P) + P * ((y % P) + P * (z % P));
+      }
+      __device__ __forceinline__ void
+      next()
+      {
+        constexpr int DZ = BLOCK / (NI * NI), DY = (BLOCK % (NI * NI)) / NI, DX = BLOCK % NI;
+        x += DX;
+        if (x > NI)
+          {
+            x -= NI;
+            ++y;
+          }
+        y += DY;
+        if (y > NI)
+          {
+            y -= NI;
+            ++z;
+          }
+        z += DZ;
+      }
+    };
+    const InteriorWalk walk0{tid % NI + 1, (tid / NI) % NI + 1, tid / (NI * NI) + 1};
+    // entry `it` exists: always below the last round
+    auto has_entry = [&](int it) -> bool { return (it + 1) * BLOCK <= G::N_INT || tid + it * BLOCK < G::N_INT; };
+    int spos[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it)
+      {
+        const int idx = tid + it * BLOCK;
+        spos[it]      = idx < G::N_SHELL ? (int)args.g.shell_pos[idx] : -1;
+      }
+    __syncthreads();
+
+    constexpr bool x_from_b = MODE == MODE_CHEB_FIRST; // x = c0 dinv b, never stored
+    // the epilogue operands (x_old, b) of a slot: requested before its sweeps (their latency hides behind the arithmetic, but
+    // they are live across the sweeps: with the second set of gathered values the Chebyshev modes then exceed 256 VGPRs), or
+    // after them, ahead of the next slot's values
+#ifndef MGAMD_PERSISTENT_EARLY_OPERANDS
+#define MGAMD_PERSISTENT_EARLY_OPERANDS 1
+#endif
+    constexpr bool EARLY_OPERANDS = MGAMD_PERSISTENT_EARLY_OPERANDS || !(MODE == MODE_CHEB || MODE == MODE_CHEB_SECOND);
+#ifndef MGAMD_PERSISTENT_MID_OPERANDS
+#define MGAMD_PERSISTENT_MID_OPERANDS 0
+#endif
+    constexpr bool MID_OPERANDS = MGAMD_PERSISTENT_MID_OPERANDS; // between the y and the x sweep
+#ifndef MGAMD_PERSISTENT_STREAMED
+#define MGAMD_PERSISTENT_STREAMED 1
+#endif
+    // slot tables of virtual block v
+    auto load_tables = [&](uint32_t v, uint32_t &slot, uint32_t &base, uint32_t(&sg)[ITERS], double &h) {
+      slot = xcd_contiguous(v, n);
+      base = args.g.interior_base[slot];
+      h    = args.g.h[slot];
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it)
+        {
+          const int idx = tid + it * BLOCK;
+          sg[it]        = args.g.shell_idx[(size_t)slot * G::N_SHELL + (idx < G::N_SHELL ? idx : 0)];
+        }
+    };
+    // operator input on the lattice of a slot (x_from_b: b and, on the shell, D^-1)
+    auto load_values = [&](uint32_t base, const uint32_t(&sg)[ITERS], T(&xv)[ITER], T(&sv)[ITERS], T(&sbv)[ITERS]) {
+      const T *__restrict__ in = x_from_b ? args.epi.b : args.src;
+#pragma unroll
+      for (int it = 0; it < ITER; ++it)
+        xv[it] = in[base + (uint32_t)(has_entry(it) ? tid + it * BLOCK : 0)];
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it)
+        {
+          const uint32_t gi = sg[it] < args.gather_limit ? sg[it] : 0;
+          sv[it]            = in[gi];
+          if (x_from_b)
+            sbv[it] = args.epi.dinv[gi];
+        }
+    };
+
+    uint32_t slot, base, sgi[ITERS];
+    double   hcur;
+    T        xg[ITER], sval[ITERS], sb[ITERS];
+    load_tables(w, slot, base, sgi, hcur);
+    load_values(base, sgi, xg, sval, sb);
+
+    for (uint32_t v = w;;)
+      {
+        const uint32_t block    = v;
+        (void)block;
+        const uint32_t vn       = v + stride;
+        const bool     has_next = vn < n;
+        MGAMD_STAMP(0)
+        const T rh = T(1) / T(hcur);
+        // D^-1 of this thread's interior entry `it`: |d| > 1e-10 ? 1/d : 1 with d = h s  (ref:include/operator.h:228-242)
+        auto interior_dinv = [&](int t) -> T { // t: node type (InteriorWalk::type)
+          return fabs((double)dtab[t]) > 1.0e-10 * fabs((double)rh) ? rh * dtab[P3 + t] : T(1);
+        };
+        // ---- values of this slot -> LDS ---------------------------------------------------------------------
+        T bv[ITER], xo[ITER];
+        if (x_from_b)
+          {
+#pragma unroll
+            for (int it = 0; it < ITER; ++it)
+              {
+                bv[it] = xg[it]; // (x itself is recomputed in the epilogue: one value less across the sweeps)
+              }
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it)
+              sval[it] = args.epi.c0 * sb[it] * sval[it];
+          }
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it)
+          if (spos[it] >= 0)
+            bufA[spos[it]] = sgi[it] < args.gather_limit ? sval[it] : T(0);
+        {
+          InteriorWalk wk = walk0;
+#pragma unroll
+          for (int it = 0; it < ITER; ++it, wk.next())
+            if (has_entry(it))
+              bufA[wk.pos()] = x_from_b ? args.epi.c0 * interior_dinv(wk.type()) * bv[it] : xg[it];
+        }
+        // ---- slot tables of the next slot, epilogue operands of this one: requested now ------------------------
+        uint32_t slotn = slot, basen = base, sgn[ITERS];
+        double   hn = hcur;
+        if (has_next)
+          load_tables(vn, slotn, basen, sgn, hn);
+        auto load_operands = [&]() {
+#pragma unroll
+          for (int it = 0; it < ITER; ++it)
+            {
+              const uint32_t g = base + (uint32_t)(has_entry(it) ? tid + it * BLOCK : 0);
+              xo[it]           = T(0);
+              if (!x_from_b)
+                bv[it] = T(0);
+              if (MODE == MODE_CHEB && args.epi.xold)
+                xo[it] = args.epi.xold[g];
+              if ((MODE == MODE_RESIDUAL || is_cheb(MODE)) && !x_from_b)
+                bv[it] = args.epi.b[g];
+            }
+        };
+        if (EARLY_OPERANDS)
+          load_operands();
+        __syncthreads();
+        MGAMD_STAMP(1)
+
+        bool any_hanging = false;
+        if constexpr (brick_may_be_constrained(B, CONSTR))
+          {
+            // constrained bricks: whole-face / whole-edge hanging nodes (uniform branch: one mask per slot)
+            uint32_t fm = 0;
+            if (args.g.fmask != nullptr && tid == 0)
+              fm = args.g.fmask[slot];
+            any_hanging = __syncthreads_or((int)(fm != 0)) != 0;
+            if (any_hanging)
+              brick_constraint_passes<T, P, B, BLOCK>(bufA, args.m, tid, 1, args.g.fmask + slot, false);
+          }
+        auto mid_hook = [&]() {
+          if (!EARLY_OPERANDS && MID_OPERANDS)
+            load_operands();
+        };
+        lattice_sweeps<T, P, B, BLOCK, decltype(mid_hook), MGAMD_PERSISTENT_STREAMED != 0>(bufA, bufB, args.m, tid, 1, &hcur, mid_hook);
+        if constexpr (brick_may_be_constrained(B, CONSTR))
+          if (any_hanging)
+            brick_constraint_passes<T, P, B, BLOCK>(bufA, args.m, tid, 1, args.g.fmask + slot, true);
+        MGAMD_STAMP(2)
+
+        // ---- values of the next slot: requested now, consumed at the top of the next iteration ------------------
+        if (!EARLY_OPERANDS && !MID_OPERANDS)
+          load_operands();
+        T xgn[ITER], svaln[ITERS], sbn[ITERS];
+        if (has_next)
+          load_values(basen, sgn, xgn, svaln, sbn);
+
+        // ---- interior DoFs are complete: fused epilogue, contiguous stores -----------------------------------
+        InteriorWalk wk = walk0;
+#pragma unroll
+        for (int it = 0; it < ITER; ++it, wk.next())
+          if (has_entry(it))
+            {
+              const uint32_t g  = base + (uint32_t)(tid + it * BLOCK);
+              const T        ax = bufA[wk.pos()];
+              T              r;
+              if (MODE == MODE_VMULT)
+                r = ax;
+              else if (MODE == MODE_RESIDUAL)
+                r = bv[it] - ax;
+              else
+                {
+                  const T dv  = interior_dinv(wk.type());
+                  const T xov = MODE == MODE_CHEB_SECOND ? args.epi.c0 * dv * bv[it] : xo[it];
+                  const T xv  = x_from_b ? args.epi.c0 * dv * bv[it] : xg[it];
+                  r           = xv + args.epi.f1 * (xv - xov) + args.epi.f2 * dv * (bv[it] - ax);
+                }
+              args.epi.out[g] = r;
+            }
+        MGAMD_STAMP(3)
+        // ---- shell DoFs: partial sums into the tail accumulator ------------------------------------------------
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it)
+          if (spos[it] >= 0 && sgi[it] < args.scatter_limit)
+            atomic_add(&args.tail_acc[sgi[it] - args.n_interior], bufA[spos[it]]);
+        MGAMD_STAMP(4)
+        if (!has_next)
+          break;
+        v    = vn;
+        slot = slotn;
+        base = basen;
+        hcur = hn;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it)
+          {
+            sgi[it]  = sgn[it];
+            sval[it] = svaln[it];
+            sb[it]   = sbn[it];
+          }
+#pragma unroll
+        for (int it = 0; it < ITER; ++it)
+          xg[it] = xgn[it];
+        __syncthreads(); // every thread has read its results of this slot from bufA
+      }
+  }
 #undef MGAMD_STAMP
 #undef MGAMD_ABLATED
 
@@ -1026,6 +1439,15 @@ namespace mgamd
   {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     lattice_apply_body<T, P, B, MODE, CONSTR>(args, blockIdx.x, gridDim.x, smem_raw);
+  }
+
+  // persistent workgroups (lattice_apply_persistent_body); the grid is the number of RESIDENT workgroups (runtime.hip)
+  template <typename T, int P, int B, int MODE, bool CONSTR = false>
+  __global__ void
+  __launch_bounds__((Geo<P, B>::ABLOCK), 2) lattice_apply_persistent_kernel(const ApplyArgs<T, P> args)
+  {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    lattice_apply_persistent_body<T, P, B, MODE, CONSTR>(args, blockIdx.x, gridDim.x, smem_raw);
   }
 
   // The plain and the constrained bricks of one size in ONE launch (same lattice, same LDS, same block size): the
@@ -1051,6 +1473,24 @@ namespace mgamd
         a.g               = args.g_constrained;
         a.stamps          = nullptr;
         lattice_apply_body<T, P, B, MODE, true>(a, blockIdx.x - args.n_wg_plain, gridDim.x - args.n_wg_plain, smem_raw);
+      }
+  }
+
+  // the pair launch with persistent workgroups: the first n_wg_plain workgroups walk the plain bricks, the others the
+  // constrained ones (both counts are multiples of 8 when a workgroup has more than one slot: runtime.hip)
+  template <typename T, int P, int B, int MODE>
+  __global__ void
+  __launch_bounds__((Geo<P, B>::ABLOCK), 2) lattice_apply_persistent_pair_kernel(const BrickPairArgs<T, P> args)
+  {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    if (blockIdx.x < args.n_wg_plain)
+      lattice_apply_persistent_body<T, P, B, MODE, false>(args.a, blockIdx.x, args.n_wg_plain, smem_raw);
+    else
+      {
+        ApplyArgs<T, P> a = args.a;
+        a.g               = args.g_constrained;
+        a.stamps          = nullptr;
+        lattice_apply_persistent_body<T, P, B, MODE, true>(a, blockIdx.x - args.n_wg_plain, gridDim.x - args.n_wg_plain, smem_raw);
       }
   }
 

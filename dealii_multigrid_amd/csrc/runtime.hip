@@ -26,6 +26,7 @@ namespace mgamd
     HIP_CHECK(hipGetDeviceProperties(&prop, dev));
     if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
       throw NoDeviceError(std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     HIP_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
     sync_events.resize(64);
@@ -298,6 +299,22 @@ namespace mgamd
       HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
 
+  // persistent workgroups for the one-slot-per-workgroup lattices (kernels.hpp, lattice_apply_persistent_body); not for
+  // float at p = 4, whose Chebyshev instantiation spills 35 registers
+  template <typename T, int P>
+  static bool
+  use_persistent()
+  {
+    static const bool on = getenv("MGAMD_NO_PERSISTENT") == nullptr;
+    return on && !(P == 4 && std::is_same<T, float>::value);
+  }
+  // two 4-wave workgroups with a 17^3 lattice pair each fit one CU; a multiple of 8 keeps a workgroup in its XCD's range
+  static int
+  resident_workgroups(const Ctx *ctx)
+  {
+    return std::max(8, 2 * ctx->n_cu / 8 * 8);
+  }
+
   template <typename T, int P, int B, int MODE, bool CONSTR = false>
   static void
   launch_lattice(Ctx *ctx, hipStream_t st, const ApplyArgs<T, P> &a, bool diag)
@@ -316,6 +333,21 @@ namespace mgamd
     else
       {
         const size_t lds  = (2 * (size_t)G::SPW * G::N3 + 2 * P * P * P + G::SPW) * sizeof(T);
+        if constexpr (G::SPW == 1 && G::N_INT > 0 && G::ROUNDS > 1)
+          {
+            // one-slot-per-workgroup lattices (17^3): persistent workgroups with a software pipeline over their slots
+            // (kernels.hpp, lattice_apply_persistent_body).  Two workgroups fit a CU (LDS); the grid is a multiple of 8 so
+            // that a workgroup stays inside the Morton range of its XCD.  MGAMD_NO_PERSISTENT=1: one workgroup per slot.
+            if (use_persistent<T, P>())
+              {
+                const int resident = resident_workgroups(ctx);
+                auto      kern     = lattice_apply_persistent_kernel<T, P, B, MODE, CONSTR>;
+                ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), lds);
+                hipLaunchKernelGGL(kern, std::min(grid, resident), G::ABLOCK, lds, st, a);
+                HIP_CHECK(hipGetLastError());
+                return;
+              }
+          }
         auto         kern = lattice_apply_kernel<T, P, B, MODE, CONSTR>;
         ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), lds);
         hipLaunchKernelGGL(kern, grid, G::ABLOCK, lds, st, a);
@@ -682,6 +714,27 @@ namespace mgamd
       pa.n_wg_plain    = (uint32_t)((a.g.n_slots + G::SPW - 1) / G::SPW);
       const uint32_t n_wg_c = (uint32_t)((g_constrained->n_slots + G::SPW - 1) / G::SPW);
       const size_t   lds    = (2 * (size_t)G::SPW * G::N3 + 2 * P * P * P + G::SPW) * sizeof(T);
+      if constexpr (G::SPW == 1 && G::N_INT > 0 && G::ROUNDS > 1)
+        if (use_persistent<T, P>())
+          {
+            // resident workgroups split by work (a constrained brick costs ~1.3 plain ones), both parts multiples of 8
+            const int    resident = resident_workgroups(ctx);
+            const double wp = (double)pa.n_wg_plain, wc = 1.3 * (double)n_wg_c;
+            uint32_t     np = pa.n_wg_plain, nc = n_wg_c;
+            if ((int)(np + nc) > resident)
+              {
+                nc = std::min<uint32_t>(n_wg_c, std::max<uint32_t>(8, (uint32_t)std::lround(resident * wc / (wp + wc) / 8.0) * 8));
+                np = std::min<uint32_t>(pa.n_wg_plain, std::max<uint32_t>(8, ((uint32_t)resident - nc) / 8 * 8));
+                if (nc < n_wg_c)
+                  nc = nc / 8 * 8 ? nc / 8 * 8 : 8;
+              }
+            pa.n_wg_plain = np;
+            auto kern     = lattice_apply_persistent_pair_kernel<T, P, B, MODE>;
+            ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), lds);
+            hipLaunchKernelGGL(kern, np + nc, G::ABLOCK, lds, st, pa);
+            HIP_CHECK(hipGetLastError());
+            return;
+          }
       auto           kern   = lattice_apply_pair_kernel<T, P, B, MODE>;
       ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), lds);
       hipLaunchKernelGGL(kern, pa.n_wg_plain + n_wg_c, G::ABLOCK, lds, st, pa);

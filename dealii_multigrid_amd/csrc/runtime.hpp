@@ -32,6 +32,7 @@ namespace mgamd
   {
     int         device = 0;
     hipStream_t stream = nullptr;
+    int         n_cu   = 256;     // compute units (grid of the persistent-workgroup kernels)
     double     *d_partial = nullptr; // 1024 block partials
     double     *d_result  = nullptr; // 8 scalars
     double     *h_result  = nullptr; // pinned
