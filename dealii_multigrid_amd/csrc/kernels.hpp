@@ -311,23 +311,46 @@ namespace mgamd
   // line_MK / line_M_KM / line_KM on whole lines, but ~35 instead of ~70 doubles in registers per thread: what lets the
   // persistent kernel keep its epilogue operands and the next slot's tables in flight across the sweeps.
   // KIND 0: A <- M a, Bb <- K a;  1: A <- M a, Bb <- K a + M b;  2: A <- scale (K a + M b)     (a from A, b from Bb)
-  template <typename T, int P, int B, int KIND>
+  // PREFETCH: the inputs of the next cell are requested before this cell's products (LDS latency under the arithmetic; 8
+  // more doubles in registers: measured -4 % on the 2-4-word passes, but the 5-word Chebyshev pass then spills)
+  template <typename T, int P, int B, int KIND, bool PREFETCH>
   __device__ __forceinline__ void
   line_stream(const Mats<P> &m, T *__restrict__ A, T *__restrict__ Bb, const int stride, const T scale)
   {
     constexpr int n = P + 1;
-    T             a[n], b[n], c1 = T(0), c2 = T(0);
+    T             a[n], b[n], an[n], bn[n], c1 = T(0), c2 = T(0);
     a[0] = A[0];
     b[0] = KIND == 0 ? T(0) : Bb[0];
-#pragma unroll
-    for (int c = 0; c < B; ++c)
+    if (PREFETCH)
       {
 #pragma unroll
         for (int j = 1; j < n; ++j)
           {
-            a[j] = A[(c * P + j) * stride];
-            if (KIND != 0)
-              b[j] = Bb[(c * P + j) * stride];
+            a[j] = A[j * stride];
+            b[j] = KIND == 0 ? T(0) : Bb[j * stride];
+          }
+      }
+#pragma unroll
+    for (int c = 0; c < B; ++c)
+      {
+        if (!PREFETCH)
+          {
+#pragma unroll
+            for (int j = 1; j < n; ++j)
+              {
+                a[j] = A[(c * P + j) * stride];
+                if (KIND != 0)
+                  b[j] = Bb[(c * P + j) * stride];
+              }
+          }
+        else if (c + 1 < B)
+          {
+#pragma unroll
+            for (int j = 1; j < n; ++j)
+              {
+                an[j] = A[((c + 1) * P + j) * stride];
+                bn[j] = KIND == 0 ? T(0) : Bb[((c + 1) * P + j) * stride];
+              }
           }
         T o1[n], o2[n];
 #pragma unroll
@@ -385,6 +408,15 @@ namespace mgamd
         c2   = o2[P];
         a[0] = a[P];
         b[0] = b[P];
+        if (PREFETCH)
+          {
+#pragma unroll
+            for (int j = 1; j < n; ++j)
+              {
+                a[j] = an[j];
+                b[j] = bn[j];
+              }
+          }
       }
     if (KIND != 2)
       {
@@ -465,7 +497,7 @@ namespace mgamd
   };
   // before_x: called between the y and the x sweep (the x sweep holds one line less in registers than the y sweep: the
   // persistent kernel requests its epilogue operands there)
-  template <typename T, int P, int B, int BLOCK, typename Hook = NoHook, bool STREAMED = false>
+  template <typename T, int P, int B, int BLOCK, typename Hook = NoHook, bool STREAMED = false, bool PREFETCH = false>
   __device__ __forceinline__ void
   lattice_sweeps(T *__restrict__ bufA, T *__restrict__ bufB, const Mats<P> &m, int tid, int nslots, const double *__restrict__ hslot,
                  const Hook &before_x = Hook())
@@ -492,7 +524,7 @@ namespace mgamd
           {
             const int base = sl * N3 + v * N + u;
             if constexpr (STREAM)
-              line_stream<T, P, B, 0>(m, bufA + base, bufB + base, N * N, T(1));
+              line_stream<T, P, B, 0, PREFETCH>(m, bufA + base, bufB + base, N * N, T(1));
             else
               {
 #pragma unroll
@@ -536,7 +568,7 @@ namespace mgamd
           {
             const int base = sl * N3 + v * N * N + u;
             if constexpr (STREAM)
-              line_stream<T, P, B, 1>(m, bufA + base, bufB + base, N, T(1));
+              line_stream<T, P, B, 1, PREFETCH>(m, bufA + base, bufB + base, N, T(1));
             else
               {
 #pragma unroll
@@ -589,7 +621,7 @@ namespace mgamd
             const T   h    = T(hslot[sl]);
             const int base = sl * N3 + (v * N + u) * N;
             if constexpr (STREAM)
-              line_stream<T, P, B, 2>(m, bufA + base, bufB + base, 1, h);
+              line_stream<T, P, B, 2, PREFETCH>(m, bufA + base, bufB + base, 1, h);
             else
               {
 #pragma unroll
@@ -1369,7 +1401,7 @@ namespace mgamd
           if (!EARLY_OPERANDS && MID_OPERANDS)
             load_operands();
         };
-        lattice_sweeps<T, P, B, BLOCK, decltype(mid_hook), MGAMD_PERSISTENT_STREAMED != 0>(bufA, bufB, args.m, tid, 1, &hcur, mid_hook);
+        lattice_sweeps<T, P, B, BLOCK, decltype(mid_hook), MGAMD_PERSISTENT_STREAMED != 0, MODE != MODE_CHEB>(bufA, bufB, args.m, tid, 1, &hcur, mid_hook);
         if constexpr (brick_may_be_constrained(B, CONSTR))
           if (any_hanging)
             brick_constraint_passes<T, P, B, BLOCK>(bufA, args.m, tid, 1, args.g.fmask + slot, true);

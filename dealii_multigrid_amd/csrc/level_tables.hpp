@@ -820,7 +820,7 @@ namespace mgamd
       // MGAMD_MAX_CONSTRAINED_BRICK=2: only families (the 8 children of one cell) may be constrained bricks (development A/B)
       // (larger constrained bricks only at p = 1: kernels.hpp brick_may_be_constrained, with the measurements)
       const int  max_constrained_brick =
-        p != 1 ? 2 : (getenv("MGAMD_MAX_CONSTRAINED_BRICK") ? std::max(2, atoi(getenv("MGAMD_MAX_CONSTRAINED_BRICK"))) : 1 << 30);
+        getenv("MGAMD_MAX_CONSTRAINED_BRICK") ? std::max(2, atoi(getenv("MGAMD_MAX_CONSTRAINED_BRICK"))) : (p != 1 ? 2 : 1 << 30);
       int        skip           = p == 1 ? 6 : 0;
       if (const char *e = getenv("MGAMD_SKIP_BRICKS")) // development: bit mask of brick sizes to leave out
         skip = atoi(e);

@@ -362,13 +362,15 @@ namespace mgamd
   {
     if (constrained)
       {
-        if constexpr (P == 1)
-          {
-            if (B == 8)
-              return launch_lattice<T, P, 8, MODE, true>(ctx, st, a, diag);
-            if (B == 16)
-              return launch_lattice<T, P, 16, MODE, true>(ctx, st, a, diag);
-          }
+        if constexpr (P * 4 + 1 <= 17)
+          if (B == 4)
+            return launch_lattice<T, P, 4, MODE, true>(ctx, st, a, diag);
+        if constexpr (P * 8 + 1 <= 17)
+          if (B == 8)
+            return launch_lattice<T, P, 8, MODE, true>(ctx, st, a, diag);
+        if constexpr (P * 16 + 1 <= 17)
+          if (B == 16)
+            return launch_lattice<T, P, 16, MODE, true>(ctx, st, a, diag);
         throw std::runtime_error("constrained bricks of this size/degree are not instantiated");
       }
     switch (B)
