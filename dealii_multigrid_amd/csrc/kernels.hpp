@@ -659,6 +659,169 @@ namespace mgamd
     __syncthreads();
   }
 
+  // ---- WIDE sweeps: 512 threads on one 17-point lattice (4 waves per SIMD with two workgroups per CU instead of 2).
+  // A sweep is 512 half-line tasks (lines 0..255, nodes 8 s .. 8 s + 7 (+ 16), s = tid & 1: the two halves of a line in
+  // adjacent lanes) followed by 132 quarter-line tasks for the 33 left-over lines (as in lattice_sweeps).  A task of SEGN
+  // nodes reads, UP FRONT, the P nodes of the cell to its left (whose last row acts on its first node) and the node to its
+  // right (owned, and overwritten early, by the next task of the line); all tasks of a line sit in one wavefront and run in
+  // lock step, so every lane has these before any lane stores (seg_fence).  Its own nodes are streamed cell by cell.
+  // KIND as in line_stream.  A, Bb point at the task's first node.
+  template <typename T, int P, int KIND, int SEGN>
+  __device__ __forceinline__ void
+  seg_task(const Mats<P> &m, T *__restrict__ A, T *__restrict__ Bb, const int stride, const bool has_left, const bool is_last,
+           const T scale)
+  {
+    static_assert(SEGN % P == 0, "segment = whole cells");
+    constexpr int n = P + 1, CPS = SEGN / P;
+    T             la[n], lb[n];
+#pragma unroll
+    for (int j = 0; j < P; ++j)
+      {
+        la[j] = has_left ? A[(j - P) * stride] : T(0);
+        lb[j] = (KIND != 0 && has_left) ? Bb[(j - P) * stride] : T(0);
+      }
+    la[P]      = A[0];
+    lb[P]      = KIND != 0 ? Bb[0] : T(0);
+    const T ra = A[SEGN * stride], rb = KIND != 0 ? Bb[SEGN * stride] : T(0);
+    seg_fence();
+    T c1 = T(0), c2 = T(0);
+#pragma unroll
+    for (int j = 0; j <= P; ++j)
+      {
+        const T Mj = T(m.M[P * (P + 1) + j]), Kj = T(m.K[P * (P + 1) + j]);
+        if (KIND != 2)
+          c1 += Mj * la[j];
+        c2 += Kj * la[j];
+        if (KIND != 0)
+          c2 += Mj * lb[j];
+      }
+    if (!has_left)
+      c1 = c2 = T(0);
+    T a[n], b[n];
+    a[0] = la[P];
+    b[0] = lb[P];
+#pragma unroll
+    for (int c = 0; c < CPS; ++c)
+      {
+#pragma unroll
+        for (int j = 1; j < n; ++j)
+          {
+            const bool right = c == CPS - 1 && j == P;
+            a[j]             = right ? ra : A[(c * P + j) * stride];
+            if (KIND != 0)
+              b[j] = right ? rb : Bb[(c * P + j) * stride];
+          }
+        T o1[n], o2[n];
+#pragma unroll
+        for (int i = 0; i < n; ++i)
+          o1[i] = o2[i] = T(0);
+        if constexpr (P < 4)
+          {
+#pragma unroll
+            for (int i = 0; i < n; ++i)
+#pragma unroll
+              for (int j = 0; j < n; ++j)
+                {
+                  if (KIND != 2)
+                    o1[i] += T(m.M[i * n + j]) * a[j];
+                  o2[i] += T(m.K[i * n + j]) * a[j];
+                  if (KIND != 0)
+                    o2[i] += T(m.M[i * n + j]) * b[j];
+                }
+          }
+        else
+          {
+            EvenOdd<T, P> xa, xb, y;
+            xa.split(a);
+            if (KIND != 0)
+              xb.split(b);
+            if (KIND != 2)
+              {
+                y.template apply<false>(m.Me, m.Mo, xa);
+                y.add_to(o1);
+              }
+            y.template apply<false>(m.Ke, m.Ko, xa);
+            if (KIND != 0)
+              y.template apply<true>(m.Me, m.Mo, xb);
+            y.add_to(o2);
+          }
+        o1[0] += c1;
+        o2[0] += c2;
+#pragma unroll
+        for (int j = 0; j < P; ++j)
+          {
+            if (KIND != 2)
+              {
+                A[(c * P + j) * stride]  = o1[j];
+                Bb[(c * P + j) * stride] = o2[j];
+              }
+            else
+              A[(c * P + j) * stride] = scale * o2[j];
+          }
+        c1   = o1[P];
+        c2   = o2[P];
+        a[0] = a[P];
+        b[0] = b[P];
+      }
+    if (is_last)
+      {
+        if (KIND != 2)
+          {
+            A[SEGN * stride]  = c1;
+            Bb[SEGN * stride] = c2;
+          }
+        else
+          A[SEGN * stride] = scale * c2;
+      }
+  }
+
+  // the three sweeps of ONE 17-point lattice with 512 threads; ends with a barrier
+  template <typename T, int P, typename Hook = NoHook>
+  __device__ __forceinline__ void
+  lattice_sweeps_wide(T *__restrict__ bufA, T *__restrict__ bufB, const Mats<P> &m, const int tid, const T h, const Hook &before_x = Hook())
+  {
+    static_assert(16 % P == 0 && 8 % P == 0 && 4 % P == 0, "17-point lattices: P in {1, 2, 4}");
+    constexpr int N = 17;
+    // half-line task: line tid / 2, half tid % 2;  quarter-line task (tid < 132): line 256 + tid / 4, quarter tid % 4
+    const int  hl = tid >> 1, hs = tid & 1, hu = hl % N, hv = hl / N;
+    const int  ql = 256 + (tid >> 2), qs = tid & 3, qu = ql % N, qv = ql / N;
+    const bool qt = tid < 4 * (N * N - 256);
+    // z sweep: line (x = u, y = v), stride N^2
+    {
+      const int base = hv * N + hu + 8 * hs * N * N;
+      seg_task<T, P, 0, 8>(m, bufA + base, bufB + base, N * N, hs > 0, hs == 1, T(1));
+      if (qt)
+        {
+          const int b2 = qv * N + qu + 4 * qs * N * N;
+          seg_task<T, P, 0, 4>(m, bufA + b2, bufB + b2, N * N, qs > 0, qs == 3, T(1));
+        }
+    }
+    __syncthreads();
+    // y sweep: line (x = u, z = v), stride N
+    {
+      const int base = hv * N * N + hu + 8 * hs * N;
+      seg_task<T, P, 1, 8>(m, bufA + base, bufB + base, N, hs > 0, hs == 1, T(1));
+      if (qt)
+        {
+          const int b2 = qv * N * N + qu + 4 * qs * N;
+          seg_task<T, P, 1, 4>(m, bufA + b2, bufB + b2, N, qs > 0, qs == 3, T(1));
+        }
+    }
+    __syncthreads();
+    before_x();
+    // x sweep: line (y = u, z = v), stride 1
+    {
+      const int base = (hv * N + hu) * N + 8 * hs;
+      seg_task<T, P, 2, 8>(m, bufA + base, bufB + base, 1, hs > 0, hs == 1, h);
+      if (qt)
+        {
+          const int b2 = (qv * N + qu) * N + 4 * qs;
+          seg_task<T, P, 2, 4>(m, bufA + b2, bufB + b2, 1, qs > 0, qs == 3, h);
+        }
+    }
+    __syncthreads();
+  }
+
   // In-cell hanging-node interpolation (transpose = false, before the sweeps) or its transpose
   // (after), for single-cell slots (N = P+1).  One thread per line; only lines on hanging
   // faces/edges do work.  Ends with a barrier.
@@ -2766,6 +2929,178 @@ namespace mgamd
           else
             atomic_add(&args.dst[cgi[it]], v);
         }
+  }
+
+  // brick_restrict_kernel with PERSISTENT workgroups (17-point fine lattices): workgroup w restricts the bricks w, w + stride,
+  // ... with the same software pipeline as lattice_apply_persistent_body: the tables of the next brick (slot -> interior base,
+  // ownership list, coarse indices) are requested before the sweeps of the current one, its values (fine residuals, old
+  // coarse values) after them.  The one-brick-per-workgroup kernel spends its life in three dependent round trips
+  // (slot -> base -> values): measured 486 us for 1.6 GB at octant p=4 L=8.
+  template <typename T, int P, int B>
+  __global__ void
+  __launch_bounds__(256, 3) brick_restrict_persistent_kernel(const BrickTransferArgs<T, P> args)
+  {
+    using G  = BrickTransferGeo<P, B>;
+    using LG = Geo<P, B>;
+    static_assert(LG::N_INT > 0, "bricks with interior nodes");
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    T *buf = reinterpret_cast<T *>(smem_raw); // NF^3 lattice, reduced in place to the coarse lattice at coordinates < NC
+    constexpr int NC = G::NC, NF = G::NF, BLOCK = G::BLOCK;
+    constexpr int NI = LG::NI, NIN = LG::N_INT;
+    constexpr int ITI = (NIN + BLOCK - 1) / BLOCK, ITS = (LG::N_SHELL + BLOCK - 1) / BLOCK, ITC = (G::NC3 + BLOCK - 1) / BLOCK;
+    const int      tid = threadIdx.x;
+    const uint32_t n = args.n_bricks, w = blockIdx.x, stride = gridDim.x;
+    if (w >= n)
+      return;
+    // loop-invariant positions
+    int  spos[ITS], cpos[ITC];
+    bool cinner[ITC];
+#pragma unroll
+    for (int it = 0; it < ITS; ++it)
+      spos[it] = tid + it * BLOCK < LG::N_SHELL ? (int)args.shell_pos[tid + it * BLOCK] : -1;
+#pragma unroll
+    for (int it = 0; it < ITC; ++it)
+      {
+        const int idx = tid + it * BLOCK;
+        const int x = idx % NC, y = (idx / NC) % NC, z = idx / (NC * NC);
+        cinner[it] = x > 0 && y > 0 && z > 0 && x < NC - 1 && y < NC - 1 && z < NC - 1;
+        cpos[it]   = idx < G::NC3 ? (z * NF + y) * NF + x : -1;
+      }
+    auto load_tables = [&](uint32_t v, uint32_t &base, uint32_t(&gi)[ITS], uint32_t(&cgi)[ITC]) {
+      const uint32_t brick = xcd_contiguous(v, n);
+      base                 = args.interior_base[args.slot[brick]];
+#pragma unroll
+      for (int it = 0; it < ITS; ++it)
+        gi[it] = spos[it] >= 0 ? args.own_shell[(size_t)brick * LG::N_SHELL + tid + it * BLOCK] : DEV_INVALID;
+#pragma unroll
+      for (int it = 0; it < ITC; ++it)
+        cgi[it] = cpos[it] >= 0 ? args.coarse_idx[(size_t)brick * G::NC3 + tid + it * BLOCK] : DEV_INVALID;
+    };
+    auto load_values = [&](uint32_t base, const uint32_t(&gi)[ITS], const uint32_t(&cgi)[ITC], T(&val)[ITI], T(&sval)[ITS], T(&cold)[ITC]) {
+#pragma unroll
+      for (int it = 0; it < ITI; ++it)
+        val[it] = args.src[base + (uint32_t)(tid + it * BLOCK < NIN ? tid + it * BLOCK : 0)];
+#pragma unroll
+      for (int it = 0; it < ITS; ++it)
+        sval[it] = args.src[gi[it] != DEV_INVALID ? gi[it] : 0];
+#pragma unroll
+      for (int it = 0; it < ITC; ++it)
+        cold[it] = args.dst[(cgi[it] != DEV_INVALID && cinner[it]) ? cgi[it] : 0];
+    };
+    uint32_t base, gi[ITS], cgi[ITC];
+    T        val[ITI], sval[ITS], cold[ITC];
+    load_tables(w, base, gi, cgi);
+    load_values(base, gi, cgi, val, sval, cold);
+    for (uint32_t v = w;;)
+      {
+        const uint32_t vn       = v + stride;
+        const bool     has_next = vn < n;
+        // fine residuals of this brick -> LDS (interior entry i = tid + it BLOCK walks the lattice as in InteriorWalk)
+        {
+          int x = tid % NI + 1, y = (tid / NI) % NI + 1, z = tid / (NI * NI) + 1;
+#pragma unroll
+          for (int it = 0; it < ITI; ++it)
+            {
+              if ((it + 1) * BLOCK <= NIN || tid + it * BLOCK < NIN)
+                buf[(z * NF + y) * NF + x] = val[it];
+              constexpr int DZ = BLOCK / (NI * NI), DY = (BLOCK % (NI * NI)) / NI, DX = BLOCK % NI;
+              x += DX;
+              if (x > NI)
+                {
+                  x -= NI;
+                  ++y;
+                }
+              y += DY;
+              if (y > NI)
+                {
+                  y -= NI;
+                  ++z;
+                }
+              z += DZ;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < ITS; ++it)
+          if (spos[it] >= 0)
+            buf[spos[it]] = gi[it] != DEV_INVALID ? sval[it] : T(0);
+        uint32_t basen = base, gin[ITS], cgn[ITC];
+        if (has_next)
+          load_tables(vn, basen, gin, cgn);
+        __syncthreads();
+        T in[NF], out[NC];
+        // x^T: lines (Y, Z)
+        for (int l = tid; l < NF * NF; l += BLOCK)
+          {
+            const int b0 = l * NF;
+#pragma unroll
+            for (int i = 0; i < NF; ++i)
+              in[i] = buf[b0 + i];
+            line_embed_T<T, P, G::BC>(args.E, in, out);
+#pragma unroll
+            for (int i = 0; i < NC; ++i)
+              buf[b0 + i] = out[i];
+          }
+        __syncthreads();
+        // y^T: lines (x, Z), x < NC
+        for (int l = tid; l < NC * NF; l += BLOCK)
+          {
+            const int b0 = (l / NC) * NF * NF + l % NC;
+#pragma unroll
+            for (int i = 0; i < NF; ++i)
+              in[i] = buf[b0 + i * NF];
+            line_embed_T<T, P, G::BC>(args.E, in, out);
+#pragma unroll
+            for (int i = 0; i < NC; ++i)
+              buf[b0 + i * NF] = out[i];
+          }
+        __syncthreads();
+        // z^T: lines (x, y), x, y < NC
+        for (int l = tid; l < NC * NC; l += BLOCK)
+          {
+            const int b0 = (l / NC) * NF + l % NC;
+#pragma unroll
+            for (int i = 0; i < NF; ++i)
+              in[i] = buf[b0 + i * NF * NF];
+            line_embed_T<T, P, G::BC>(args.E, in, out);
+#pragma unroll
+            for (int i = 0; i < NC; ++i)
+              buf[b0 + i * NF * NF] = out[i];
+          }
+        __syncthreads();
+        T valn[ITI], svaln[ITS], coldn[ITC];
+        if (has_next)
+          load_values(basen, gin, cgn, valn, svaln, coldn);
+#pragma unroll
+        for (int it = 0; it < ITC; ++it)
+          if (cgi[it] != DEV_INVALID)
+            {
+              const T r = buf[cpos[it]];
+              if (cinner[it])
+                args.dst[cgi[it]] = cold[it] + r; // only this patch touches coarse nodes strictly inside it
+              else
+                atomic_add(&args.dst[cgi[it]], r);
+            }
+        if (!has_next)
+          break;
+        v    = vn;
+        base = basen;
+#pragma unroll
+        for (int it = 0; it < ITS; ++it)
+          {
+            gi[it]   = gin[it];
+            sval[it] = svaln[it];
+          }
+#pragma unroll
+        for (int it = 0; it < ITC; ++it)
+          {
+            cgi[it]  = cgn[it];
+            cold[it] = coldn[it];
+          }
+#pragma unroll
+        for (int it = 0; it < ITI; ++it)
+          val[it] = valn[it];
+        __syncthreads(); // every thread has read its coarse results from buf
+      }
   }
 
   // ------------------------------------------------------------------------------------------

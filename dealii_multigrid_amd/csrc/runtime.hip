@@ -1619,6 +1619,17 @@ namespace mgamd
             }
           hipLaunchKernelGGL(kern, (int)b.n_bricks, G::BLOCK, lds, ctx->stream, a);
         }
+      else if (G::NF == 17 && getenv("MGAMD_NO_PERSISTENT") == nullptr)
+        {
+          // persistent workgroups, three per CU (<= 168 VGPRs), a multiple of 8 (kernels.hpp)
+          if constexpr (G::NF == 17)
+            {
+              auto kern = brick_restrict_persistent_kernel<T, P, B>;
+              ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), lds);
+              const int resident = std::max(8, 3 * ctx->n_cu / 8 * 8);
+              hipLaunchKernelGGL(kern, std::min((int)b.n_bricks, resident), G::BLOCK, lds, ctx->stream, a);
+            }
+        }
       else
         {
           auto        kern = brick_restrict_kernel<T, P, B>;
