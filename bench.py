@@ -77,7 +77,7 @@ def run_workload(m, ctx, geometry, n_ref, degree, mg_type, coarse, steps, warmup
     elapsed = time.perf_counter() - t0
     prof = None
     if profile:
-        prof = ctx.kernel_profile_read()
+        prof = ctx.kernel_profile_read() + (ctx.kernel_profile_bytes_moved(),)
         ctx.kernel_profile(False)
     if comm is None:
         N = [d.n_dofs for d in h.dofs]
@@ -136,7 +136,8 @@ def pmc_traffic(n_ref, B):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_traffic_octant{n_ref}_p4.json")))
     if not files:
         return None, None
-    rows = [r for r in json.load(open(files[-1]))["kernels"] if f"lattice_apply_kernel<double, 4, {B}, 2" in r["kernel"]]
+    rows = [r for r in json.load(open(files[-1]))["kernels"]
+            if f"lattice_apply_kernel<double, 4, {B}, 2" in r["kernel"] or f"lattice_apply_persistent_kernel<double, 4, {B}, 2" in r["kernel"]]
     for r in rows:  # tools/pmc_vcycle.py (round 2) counts launches per V-cycle, tools/pmc_summary.py (round 1) per run
         r.setdefault("launches", r.get("launches_per_cycle", 0))
     n = sum(r["launches"] for r in rows)
@@ -325,17 +326,19 @@ def main():
                                  "traffic; this implementation never stores x_1 of the zero-start smoother and moves 5 words per DoF and "
                                  "level fewer, so this fraction is the model's bytes over time, not achieved bandwidth)")
     if prim["prof"] and prim["prof"][1] > 0:
-        ms, n, by = prim["prof"]
+        ms, n, by, by_moved = prim["prof"]
         achieved = by / (ms * 1e-3) / 1e9
         B = max(prim["groups"], key=lambda g: g[1] * (degree * g[0] + 1) ** 3)[0]
         traffic, traffic_src = pmc_traffic(nref, B) if args.workload == "octant_p4" else (None, None)
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                            "traffic": traffic, "traffic_source": traffic_src,
-                           "kernel": f"lattice_apply_kernel<double,{degree},{B},MODE_CHEB> (the Chebyshev passes that read x and x_old from memory; all "
-                                     f"launches of this symbol in the timed region).  Algorithmic bytes per brick: 5 (4 without x_old) words x "
-                                     f"{(degree * B - 1) ** 3} slot-interior DoFs + 2 words (gathered x, partial sum) x {(degree * B) ** 3 - (degree * B - 1) ** 3} shell DoFs "
-                                     f"whose epilogue tail_kernel finishes",
-                           "launches": n, "avg_launch_us": ms / n * 1e3, "algorithmic_bytes_per_launch": by / n}
+                           "kernel": f"lattice_apply_persistent_kernel<double,{degree},{B},MODE_CHEB> (the Chebyshev passes that read x and x_old from memory; all "
+                                     f"launches of this symbol in the timed region).  Algorithmic bytes per brick (SURVEY 8(d) per-unit figure): 5 (4 "
+                                     f"without x_old) words (x, x_old, b, D^-1, out) x {(degree * B - 1) ** 3} slot-interior DoFs + 2 words (gathered x, "
+                                     f"partial sum) x {(degree * B) ** 3 - (degree * B - 1) ** 3} shell DoFs whose epilogue tail_kernel finishes.  The kernel "
+                                     f"itself evaluates the interior D^-1 in closed form instead of reading it: `achieved_moved` counts 4 (3) words",
+                           "launches": n, "avg_launch_us": ms / n * 1e3, "algorithmic_bytes_per_launch": by / n,
+                           "achieved_moved": by_moved / (ms * 1e-3) / 1e9, "moved_bytes_per_launch": by_moved / n}
         if "pass_level" in prim:
             pl = dict(prim["pass_level"])
             pl["frac"] = pl["achieved_GBps"] / HBM_PEAK_GBS

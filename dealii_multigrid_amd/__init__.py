@@ -293,6 +293,11 @@ class Context:
         _chk(_lib.mgamd_ctx_kernel_profile_read(self._h, C.byref(ms), C.byref(n), C.byref(b)))
         return ms.value, n.value, b.value
 
+    def kernel_profile_bytes_moved(self):
+        b = C.c_double()
+        _chk(_lib.mgamd_ctx_kernel_profile_bytes_moved(self._h, C.byref(b)))
+        return b.value
+
     def __del__(self):
         if getattr(self, "_h", None) and _lib is not None:
             _lib.mgamd_ctx_destroy(self._h)

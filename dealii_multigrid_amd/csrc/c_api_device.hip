@@ -706,6 +706,7 @@ mgamd_ctx_kernel_profile(mgamd_ctx *ctx, int enable)
   c.prof_ms_accum = 0;
   c.prof_n_accum  = 0;
   c.prof_bytes    = 0;
+  c.prof_bytes_moved = 0;
   MGAMD_CATCH
 }
 
@@ -731,6 +732,16 @@ mgamd_ctx_kernel_profile_read(mgamd_ctx *ctx, double *total_ms, uint64_t *n_laun
     *n_launches = c.prof_n_accum;
   if (algorithmic_bytes)
     *algorithmic_bytes = c.prof_bytes;
+  MGAMD_CATCH
+}
+
+int
+mgamd_ctx_kernel_profile_bytes_moved(mgamd_ctx *ctx, double *bytes_moved)
+{
+  MGAMD_TRY
+  REQUIRE(ctx);
+  REQUIRE(bytes_moved);
+  *bytes_moved = ctx->ctx->prof_bytes_moved;
   MGAMD_CATCH
 }
 

@@ -500,7 +500,7 @@ namespace mgamd
   template <typename T, int P, int B, int BLOCK, typename Hook = NoHook, bool STREAMED = false, bool PREFETCH = false>
   __device__ __forceinline__ void
   lattice_sweeps(T *__restrict__ bufA, T *__restrict__ bufB, const Mats<P> &m, int tid, int nslots, const double *__restrict__ hslot,
-                 const Hook &before_x = Hook())
+                 const Hook &before_x = Hook(), const bool h_is_mine = false) // h_is_mine: hslot[0] is the h of THIS thread's line
   {
     using G              = Geo<P, B>;
     constexpr int N      = G::N;
@@ -618,7 +618,7 @@ namespace mgamd
         const int l = tid + r * BLOCK, sl = l / G::LINES, ln = l % G::LINES, u = ln % N, v = ln / N;
         if (l < TOT && sl < nslots)
           {
-            const T   h    = T(hslot[sl]);
+            const T   h    = T(h_is_mine ? hslot[0] : hslot[sl]);
             const int base = sl * N3 + (v * N + u) * N;
             if constexpr (STREAM)
               line_stream<T, P, B, 2, PREFETCH>(m, bufA + base, bufB + base, 1, h);
@@ -899,7 +899,8 @@ namespace mgamd
   // One thread per line (sl, u, v) as in the sweeps, in rounds of BLOCK lines.  Ends with a barrier.
   template <typename T, int P, int B, int BLOCK>
   __device__ __forceinline__ void
-  brick_constraint_passes(T *__restrict__ buf, const Mats<P> &m, int tid, int nslots, const uint32_t *__restrict__ fmask, bool transpose)
+  brick_constraint_passes(T *__restrict__ buf, const Mats<P> &m, int tid, int nslots, const uint32_t *__restrict__ fmask, bool transpose,
+                          const uint32_t *fm_mine = nullptr) // fm_mine: the mask of this thread's (only) line, already in a register
   {
     using G               = Geo<P, B>;
     constexpr int N       = G::N;
@@ -915,7 +916,10 @@ namespace mgamd
     for (int r = 0; r < ROUNDS; ++r)
       {
         const int l = tid + r * BLOCK, sl = l / G::LINES;
-        fmr[r]      = (l < TOT && sl < nslots && fmask != nullptr) ? fmask[sl] : 0u;
+        if (ROUNDS == 1 && fm_mine != nullptr)
+          fmr[r] = *fm_mine;
+        else
+          fmr[r] = (l < TOT && sl < nslots && fmask != nullptr) ? fmask[sl] : 0u;
       }
 #pragma unroll
     for (int dd = 0; dd < 3; ++dd)
@@ -1067,6 +1071,23 @@ namespace mgamd
     const int slot0  = (int)xcd_contiguous(block, nblocks) * G::SPW;
     const int nslots = min((int)G::SPW, (int)args.g.n_slots - slot0);
     MGAMD_STAMP(0)
+    // per-slot scalars of this thread's line (hanging-node mask, constraint mask, cell size): requested with the gather, not
+    // between the barriers that follow it (each was a full memory round trip on the critical path of the small-slot kernels)
+    const int  sl = tid / G::LINES, ln = tid % G::LINES;
+    const int  u = ln % G::N, v = ln / G::N;
+    const bool act = tid < G::SPW * G::LINES && sl < nslots;
+    uint32_t   mask = 0;
+    if (B == 1 && act)
+      mask = args.g.mask[slot0 + sl];
+    uint32_t fm_early = 0;
+    if constexpr (brick_may_be_constrained(B, CONSTR))
+      if (args.g.fmask != nullptr && tid < nslots)
+        fm_early = args.g.fmask[slot0 + tid];
+    const double h_mine = G::ROUNDS == 1 ? args.g.h[slot0 + (act ? sl : 0)] : 0.0;
+    uint32_t     fm_line = 0; // constraint mask of this thread's line (one line per thread when ROUNDS == 1)
+    if constexpr (brick_may_be_constrained(B, CONSTR) && G::ROUNDS == 1)
+      if (args.g.fmask != nullptr && act)
+        fm_line = args.g.fmask[slot0 + sl];
 
     // D^-1 of slot-interior DoFs is not read from memory: they only see this slot's cells, so their diagonal is the
     // closed tensor form  d = h (k_x m_y m_z + m_x k_y m_z + m_x m_y k_z)  of the assembled 1D diagonals (what
@@ -1248,12 +1269,6 @@ namespace mgamd
     MGAMD_STAMP(1)
 
     // ---- hanging-node interpolation (single-cell slots only) ---------------------------------------------
-    const int sl = tid / G::LINES, ln = tid % G::LINES;
-    const int u = ln % G::N, v = ln / G::N;
-    const bool act  = tid < G::SPW * G::LINES && sl < nslots;
-    uint32_t   mask = 0;
-    if (B == 1 && act)
-      mask = args.g.mask[slot0 + sl];
     bool any_hanging = false;
     if (B == 1)
       {
@@ -1269,22 +1284,24 @@ namespace mgamd
     if constexpr (brick_may_be_constrained(B, CONSTR))
       {
         // constrained bricks: whole-face / whole-edge hanging nodes (uniform branch: one mask per slot)
-        uint32_t fm = 0;
-        if (args.g.fmask != nullptr && tid < nslots)
-          fm = args.g.fmask[slot0 + tid];
-        any_hanging = __syncthreads_or((int)(fm != 0)) != 0;
+        any_hanging = __syncthreads_or((int)(fm_early != 0)) != 0;
         if (any_hanging)
-          brick_constraint_passes<T, P, B, BLOCK>(bufA, args.m, tid, nslots, args.g.fmask + slot0, false);
+          brick_constraint_passes<T, P, B, BLOCK>(bufA, args.m, tid, nslots, args.g.fmask + slot0, false, G::ROUNDS == 1 ? &fm_line : nullptr);
       }
 
     if (!MGAMD_ABLATED(1))
-      lattice_sweeps<T, P, B, BLOCK>(bufA, bufB, args.m, tid, nslots, args.g.h + slot0);
+      {
+        if constexpr (G::ROUNDS == 1)
+          lattice_sweeps<T, P, B, BLOCK>(bufA, bufB, args.m, tid, nslots, &h_mine, NoHook(), true);
+        else
+          lattice_sweeps<T, P, B, BLOCK>(bufA, bufB, args.m, tid, nslots, args.g.h + slot0);
+      }
 
     if (B == 1 && any_hanging)
       hanging_passes<T, P>(bufA, args.m, sl, u, v, act, mask, true);
     if constexpr (brick_may_be_constrained(B, CONSTR))
       if (any_hanging)
-        brick_constraint_passes<T, P, B, BLOCK>(bufA, args.m, tid, nslots, args.g.fmask + slot0, true);
+        brick_constraint_passes<T, P, B, BLOCK>(bufA, args.m, tid, nslots, args.g.fmask + slot0, true, G::ROUNDS == 1 ? &fm_line : nullptr);
     MGAMD_STAMP(2)
 
     // ---- interior DoFs are complete: fused epilogue, contiguous stores -----------------------------------

@@ -939,8 +939,14 @@ namespace mgamd
         // algorithmic bytes of THIS kernel: `words` per slot-interior DoF (the fused epilogue is complete for them); for
         // the (N-1)^3 - (N-2)^3 shell DoFs a brick is responsible for, one gathered word and one partial sum (the other
         // words of their epilogue are tail_kernel's)
+        // (D^-1 of slot-interior DoFs is evaluated in closed form, not read, by the p = 1 kernels and by the persistent
+        // 17-point lattice kernels: one word less per interior DoF)
+        // prof_bytes keeps SURVEY 8(d)'s per-unit figure (the algorithm's words); prof_bytes_moved is the kernel's own count
+        const bool   closed_dinv = P == 1 || (g.N * g.N > 256 && use_persistent<T, P>());
+        const double w_interior  = words - (closed_dinv ? 1.0 : 0.0);
         const double n1 = (double)(g.N - 1), n2 = (double)(g.N - 2);
         ctx->prof_bytes += sizeof(T) * (double)n_slots * (words * n2 * n2 * n2 + 2.0 * (n1 * n1 * n1 - n2 * n2 * n2));
+        ctx->prof_bytes_moved += sizeof(T) * (double)n_slots * (w_interior * n2 * n2 * n2 + 2.0 * (n1 * n1 * n1 - n2 * n2 * n2));
       };
       // plain + constrained bricks of one size share a launch (p = 1: the only degree with constrained bricks above B = 2)
       auto constrained_partner = [&](GroupDev<T> *g) -> GroupDev<T> * {

@@ -42,7 +42,8 @@ namespace mgamd
     int                                            prof_brick = 0; // 0: the dominant group of each level; B: groups of B^3 bricks only
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
     size_t                                         prof_used  = 0;
-    double                                         prof_bytes = 0.0;
+    double                                         prof_bytes = 0.0;       // SURVEY 8(d) figure: the algorithm's words
+    double                                         prof_bytes_moved = 0.0; // what the kernels are written to move (closed-form D^-1)
     double                                         prof_ms_accum = 0.0; // already harvested
     uint64_t                                       prof_n_accum  = 0;
 

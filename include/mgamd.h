@@ -312,6 +312,9 @@ int mgamd_ctx_kernel_profile(mgamd_ctx *ctx, int enable);
  * brick_size = B only groups of B^3-cell bricks, i.e. the launches of ONE kernel symbol (what rocprofv3 averages) */
 int mgamd_ctx_kernel_profile_brick(mgamd_ctx *ctx, int brick_size);
 int mgamd_ctx_kernel_profile_read(mgamd_ctx *ctx, double *total_ms, uint64_t *n_launches, double *algorithmic_bytes);
+/* the bytes the measured launches are written to move themselves (the slot-interior D^-1 is evaluated in closed form by the
+ * p = 1 and the persistent 17-point lattice kernels, one word less than SURVEY 8(d)'s figure in `algorithmic_bytes`) */
+int mgamd_ctx_kernel_profile_bytes_moved(mgamd_ctx *ctx, double *bytes_moved);
 
 #ifdef __cplusplus
 }

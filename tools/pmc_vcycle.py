@@ -4,7 +4,7 @@
 gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports exactly 1/2 of the bytes of wide coalesced
 streaming reads -> doubled here; WRITE_SIZE is exact; both in KiB.  Calibrated in the same run on vec_sadd_kernel (reads 2
 words, writes 1 word per entry): the corrected numbers must give read/write = 2.0 and read = 16 B x n."""
-import csv, json, re, sys
+import csv, json, math, re, sys
 from collections import defaultdict
 
 MARK = 304 * 256
@@ -33,17 +33,30 @@ def name(r):
 
 
 fetch, write, cycles, out = load(sys.argv[1]), load(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+# Persistent kernels launch the same grid on every level: the two passes issue the same dispatch sequence, so dispatch i of
+# the fetch window and dispatch i of the write window are the same launch; launches of one symbol and grid whose fetched
+# bytes differ by more than ~3x (levels differ by 8x in size) are kept in separate rows.
 agg = defaultdict(lambda: [0.0, 0.0, 0])
-for r in window(fetch):
-    a = agg[(name(r), r["Grid_Size"] // 256)]
-    a[0] += r["Counter_Value"] * 1024 * 2
-    a[2] += 1
-for r in window(write):
-    agg[(name(r), r["Grid_Size"] // 256)][1] += r["Counter_Value"] * 1024
+wf, ww = window(fetch), window(write)
+assert len(wf) == len(ww), "the two passes saw different dispatch sequences"
+pairs = defaultdict(list)
+for rf, rw in zip(wf, ww):
+    assert name(rf) == name(rw) and rf["Grid_Size"] == rw["Grid_Size"]
+    pairs[(name(rf), rf["Grid_Size"] // 256)].append((rf["Counter_Value"], rw["Counter_Value"]))
+for (k, g), lst in pairs.items():  # split where the sorted fetch counts jump by > 2.5x
+    lst.sort()
+    c = 0
+    for i, (f, w) in enumerate(lst):
+        if i and f > 2.5 * max(lst[i - 1][0], 1.0):
+            c += 1
+        a = agg[(k, g, c)]
+        a[0] += f * 1024 * 2
+        a[1] += w * 1024
+        a[2] += 1
 cal_r = [r["Counter_Value"] * 2048 for r in fetch if "vec_sadd_kernel" in r["Kernel_Name"]]
 cal_w = [r["Counter_Value"] * 1024 for r in write if "vec_sadd_kernel" in r["Kernel_Name"]]
 rows = []
-for (k, g), (rd, wr, n) in sorted(agg.items(), key=lambda kv: -(kv[1][0] + kv[1][1])):
+for (k, g, _), (rd, wr, n) in sorted(agg.items(), key=lambda kv: -(kv[1][0] + kv[1][1])):
     rows.append({"kernel": k, "workgroups": g, "launches_per_cycle": n / cycles, "read_bytes_per_launch": rd / n, "write_bytes_per_launch": wr / n,
                  "hbm_bytes_per_launch": (rd + wr) / n, "hbm_bytes_per_cycle": (rd + wr) / cycles})
 tot = sum(r["hbm_bytes_per_cycle"] for r in rows)
