@@ -905,9 +905,12 @@ namespace mgamd
               for (auto &g : groups)
                 launch_range(g.get(), 0, halo_end(*g));
               ctx->order_after(ctx->side, ctx->stream); // the side queue waits for the halo slots only
+              // the exchange is enqueued BEFORE the interior slots: their persistent workgroups fill every CU's LDS until the
+              // launch ends, so RCCL's send/recv kernels must be resident first to run underneath them (the simulator's
+              // exchange blocks the host instead: no overlap there, same results)
+              exchange_add_raw(tail_acc.p, ctx->side);
               for (auto &g : groups)
                 launch_range(g.get(), halo_end(*g), g->n_slots);
-              exchange_add_raw(tail_acc.p, ctx->side); // (enqueued after the interior slots: the simulator's exchange blocks the host)
               ctx->order_after(ctx->stream, ctx->side);
               launch_tail<MODE>(ctx->stream, 0, tail_end, true, epi, diag);
               return;
