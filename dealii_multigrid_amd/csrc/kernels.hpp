@@ -108,6 +108,10 @@ namespace mgamd
     const T *dinv;
     T        f1, f2;
     T        c0; // MODE_CHEB_FIRST / MODE_CHEB_SECOND
+    // tail_kernel only: D^-1 of the tail / constrained DoFs as a one-byte code into a table of the 255 most frequent values
+    // of this level (255: read dinv[]); entry i belongs to DoF n_interior + i.  Bit-identical values, 7 bytes less per DoF.
+    const uint8_t *dinv_code  = nullptr;
+    const T       *dinv_table = nullptr;
   };
   constexpr bool
   is_cheb(int mode)
@@ -2101,6 +2105,13 @@ namespace mgamd
     constexpr int  U      = 4;
     const uint32_t total  = n_tail + n_rest;
     const uint32_t stride = gridDim.x * blockDim.x;
+    __shared__ T   dtable[256];
+    const bool     coded = is_cheb(MODE) && epi.dinv_code != nullptr;
+    if (coded)
+      {
+        dtable[threadIdx.x] = epi.dinv_table[threadIdx.x]; // 256 threads
+        __syncthreads();
+      }
     for (uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < total; i0 += U * stride)
       {
         T ax[U], xv[U], xo[U], bv[U], dv[U];
@@ -2121,7 +2132,13 @@ namespace mgamd
                   {
                     if (MODE == MODE_CHEB && epi.xold)
                       xo[u] = epi.xold[gi];
-                    dv[u] = epi.dinv[gi];
+                    if (coded)
+                      {
+                        const uint32_t c = epi.dinv_code[i];
+                        dv[u]            = c != 255u ? dtable[c] : epi.dinv[gi];
+                      }
+                    else
+                      dv[u] = epi.dinv[gi];
                   }
               }
           }

@@ -6,6 +6,9 @@
 #include <cmath>
 #include <mutex>
 #include <set>
+#include <unordered_map>
+#include <cstring>
+#include <type_traits>
 
 namespace mgamd
 {
@@ -490,6 +493,10 @@ namespace mgamd
     int                                       p = 1;
     std::vector<std::unique_ptr<GroupDev<T>>> groups;
     DBuf<T>                                   tail_acc;
+    // D^-1 codes of the tail / constrained DoFs for tail_kernel (kernels.hpp, Epilogue::dinv_code), valid for the vector dinv_coded
+    DBuf<uint8_t>                             dinv_code;
+    DBuf<T>                                   dinv_table;
+    const T                                  *dinv_coded = nullptr;
     int                                       prof_B = 0; // brick size whose CHEB launches are profiled
     uint32_t                                  ablate = 0; // debug: MGAMD_ABLATE
     DBuf<unsigned long long>                  stamps;     // debug: MGAMD_STAMPS=<mode>, 8 stamps per workgroup of the largest group
@@ -803,12 +810,15 @@ namespace mgamd
 
     template <int MODE>
     void
-    launch_tail(hipStream_t st, uint32_t begin, uint32_t end, bool with_rest, const Epilogue<T> &epi, bool diag)
+    launch_tail(hipStream_t st, uint32_t begin, uint32_t end, bool with_rest, const Epilogue<T> &epi_in, bool diag)
     {
       const uint32_t n_rest = with_rest ? tables->n_dofs - tables->n_interior - end : 0;
       const uint32_t n_t    = end - begin + n_rest;
       if (!n_t)
         return;
+      Epilogue<T> epi = epi_in;
+      if (epi.dinv_code)
+        epi.dinv_code += begin;
       if (diag)
         hipLaunchKernelGGL((tail_kernel<T, MODE_INVDIAG>), grid_for(n_t), 256, 0, st, tail_acc.p + begin, tables->n_interior + begin, end - begin,
                            n_rest, epi);
@@ -1077,11 +1087,66 @@ namespace mgamd
       interface_up_raw(dst.as<T>(), src.as<T>(), tmp.p);
       ctx->sync();
     }
+    // One-byte codes for D^-1 of the DoFs tail_kernel handles (tail, refinement-edge, Dirichlet, hanging): on a level only a
+    // few hundred distinct values occur there (node type x cell size x summation order), so the 255 most frequent ones go
+    // into a table and the rest keeps reading the vector.  Values are matched by bit pattern: results do not change.
+    void
+    build_dinv_codes(const T *dinv)
+    {
+      dinv_coded = nullptr;
+      if (getenv("MGAMD_NO_DINV_CODES"))
+        return;
+      const size_t n0 = tables->n_interior, n = (size_t)n_dofs() - n0;
+      if (n < 4096) // small levels are latency-bound: nothing to gain
+        return;
+      std::vector<T> h(n);
+      ctx->sync();
+      HIP_CHECK(hipMemcpy(h.data(), dinv + n0, n * sizeof(T), hipMemcpyDeviceToHost));
+      using Bits = typename std::conditional<sizeof(T) == 8, uint64_t, uint32_t>::type;
+      std::unordered_map<Bits, uint32_t> count;
+      count.reserve(1024);
+      auto bits = [](T v) {
+        Bits b;
+        std::memcpy(&b, &v, sizeof(T));
+        return b;
+      };
+      for (size_t i = 0; i < n && count.size() < (1u << 20); ++i)
+        ++count[bits(h[i])];
+      std::vector<std::pair<uint32_t, Bits>> top;
+      top.reserve(count.size());
+      for (auto &kv : count)
+        top.push_back({kv.second, kv.first});
+      std::sort(top.begin(), top.end(), [](const auto &a, const auto &b) { return a.first > b.first || (a.first == b.first && a.second < b.second); });
+      if (top.size() > 255)
+        top.resize(255);
+      std::vector<T>                    table(256, T(1));
+      std::unordered_map<Bits, uint8_t> code_of;
+      for (size_t k = 0; k < top.size(); ++k)
+        {
+          std::memcpy(&table[k], &top[k].second, sizeof(T));
+          code_of[top[k].second] = (uint8_t)k;
+        }
+      std::vector<uint8_t> codes(n);
+      for (size_t i = 0; i < n; ++i)
+        {
+          auto it  = code_of.find(bits(h[i]));
+          codes[i] = it == code_of.end() ? (uint8_t)255 : it->second;
+        }
+      dinv_code.upload(codes);
+      dinv_table.upload(table);
+      dinv_coded = dinv;
+    }
+
     void
     cheb_raw(T *out, const T *x, const T *xold, const T *b, const T *dinv, double f1, double f2, int from_b = 0, double c0 = 0.0)
     {
       // from_b = 1: x is c0 dinv b and xold = 0 (x is not read); from_b = 2: xold is c0 dinv b (xold is not read)
       Epilogue<T> e{out, x, from_b ? nullptr : xold, b, dinv, T(f1), T(f2), T(c0)};
+      if (dinv == dinv_coded && dinv_code.p)
+        {
+          e.dinv_code  = dinv_code.p;
+          e.dinv_table = dinv_table.p;
+        }
       if (from_b == 1)
         apply<MODE_CHEB_FIRST>(x, e, false, 3.0);
       else if (from_b == 2)
@@ -1237,6 +1302,7 @@ namespace mgamd
           }
         dv.data = nullptr;
       }
+      o->build_dinv_codes(dinv.p);
       estimate_eigenvalues(smoothing_range, eig_cg_n_iterations);
     }
 
