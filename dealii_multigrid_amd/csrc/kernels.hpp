@@ -1362,7 +1362,7 @@ namespace mgamd
   //     after    the VALUES of v' are requested (the registers of the sweeps are free again), then epilogue + atomics of v
   // so both round trips of the next gather overlap with work of the current slot.  D^-1 of interior DoFs always in closed
   // form (see lattice_apply_body): that is what frees the registers for the second set of gathered values.
-  template <typename T, int P, int B, int MODE, bool CONSTR = false>
+  template <typename T, int P, int B, int MODE, bool CONSTR = false, int BLOCK_ = Geo<P, B>::ABLOCK>
   __device__ __forceinline__ void
   lattice_apply_persistent_body(const ApplyArgs<T, P> &args, const uint32_t w, const uint32_t stride, unsigned char *smem_raw)
   {
@@ -1373,8 +1373,10 @@ namespace mgamd
     T *bufB = bufA + G::N3;
     T *dtab = bufB + G::N3; // [P^3] s = d/h, [P^3] 1/s
 
-    constexpr int BLOCK = G::ABLOCK;
-    constexpr int ITER  = IM::ITER;
+    constexpr int  BLOCK = BLOCK_;
+    constexpr bool WIDE  = BLOCK == 512; // 512 threads: half-line sweeps (lattice_sweeps_wide), <= 128 VGPRs
+    static_assert(BLOCK == G::ABLOCK || (WIDE && G::N == 17 && !CONSTR), "block size");
+    constexpr int ITER  = (G::N_INT + BLOCK - 1) / BLOCK;
     constexpr int ITERS = (G::N_SHELL + BLOCK - 1) / BLOCK;
     constexpr int P3    = P * P * P;
 
@@ -1585,7 +1587,10 @@ namespace mgamd
           if (!EARLY_OPERANDS && MID_OPERANDS)
             load_operands();
         };
-        lattice_sweeps<T, P, B, BLOCK, decltype(mid_hook), MGAMD_PERSISTENT_STREAMED != 0, MODE != MODE_CHEB>(bufA, bufB, args.m, tid, 1, &hcur, mid_hook);
+        if constexpr (WIDE)
+          lattice_sweeps_wide<T, P>(bufA, bufB, args.m, tid, T(hcur), mid_hook);
+        else
+          lattice_sweeps<T, P, B, BLOCK, decltype(mid_hook), MGAMD_PERSISTENT_STREAMED != 0, MODE != MODE_CHEB>(bufA, bufB, args.m, tid, 1, &hcur, mid_hook);
         if constexpr (brick_may_be_constrained(B, CONSTR))
           if (any_hanging)
             brick_constraint_passes<T, P, B, BLOCK>(bufA, args.m, tid, 1, args.g.fmask + slot, true);
@@ -1692,6 +1697,9 @@ namespace mgamd
       }
   }
 
+  // (A 512-thread instantiation of the body with lattice_sweeps_wide - 4 waves per SIMD, <= 128 VGPRs - was measured on MI355X:
+  // the sweeps alone are 19 % faster (tools/sweep_probe.hip), the kernel is not: vmult 950 -> 964 us per pass, and the
+  // Chebyshev modes spill (6.2 instead of 4.4 ms per step()); BLOCK_ = 512 still compiles for such experiments.)
   // the pair launch with persistent workgroups: the first n_wg_plain workgroups walk the plain bricks, the others the
   // constrained ones (both counts are multiples of 8 when a workgroup has more than one slot: runtime.hip)
   template <typename T, int P, int B, int MODE>
