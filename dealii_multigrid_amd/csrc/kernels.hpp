@@ -1730,7 +1730,7 @@ namespace mgamd
   };
   template <typename T, int P, int MODE>
   __global__ void
-  __launch_bounds__(256) lattice_apply_small_kernel(const SmallSlotsArgs<T, P> args)
+  __launch_bounds__(256, 4) lattice_apply_small_kernel(const SmallSlotsArgs<T, P> args)
   {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     if (blockIdx.x < args.n_wg_bricks)
@@ -2720,7 +2720,7 @@ namespace mgamd
 
   template <typename T, int P, int B>
   __global__ void
-  __launch_bounds__(256) brick_prolongate_kernel(const BrickTransferArgs<T, P> args)
+  __launch_bounds__(256, 4) brick_prolongate_kernel(const BrickTransferArgs<T, P> args)
   {
     using G  = BrickTransferGeo<P, B>;
     using LG = Geo<P, B>;
