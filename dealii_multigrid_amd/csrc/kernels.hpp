@@ -1656,7 +1656,7 @@ namespace mgamd
 
   template <typename T, int P, int B, int MODE, bool CONSTR = false>
   __global__ void
-  __launch_bounds__((Geo<P, B>::ABLOCK), (Geo<P, B>::ROUNDS > 1 ? 2 : (B == 1 ? 6 : 1))) lattice_apply_kernel(const ApplyArgs<T, P> args)
+  __launch_bounds__((Geo<P, B>::ABLOCK), (Geo<P, B>::ROUNDS > 1 ? 2 : (B == 1 ? 6 : (B == 2 ? 4 : 1)))) lattice_apply_kernel(const ApplyArgs<T, P> args)
   {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     lattice_apply_body<T, P, B, MODE, CONSTR>(args, blockIdx.x, gridDim.x, smem_raw);
