@@ -1700,14 +1700,26 @@ namespace mgamd
   // (A 512-thread instantiation of the body with lattice_sweeps_wide - 4 waves per SIMD, <= 128 VGPRs - was measured on MI355X:
   // the sweeps alone are 19 % faster (tools/sweep_probe.hip), the kernel is not: vmult 950 -> 964 us per pass, and the
   // Chebyshev modes spill (6.2 instead of 4.4 ms per step()); BLOCK_ = 512 still compiles for such experiments.)
-  // the pair launch with persistent workgroups: the first n_wg_plain workgroups walk the plain bricks, the others the
-  // constrained ones (both counts are multiples of 8 when a workgroup has more than one slot: runtime.hip)
+  // the pair launch with persistent workgroups.  n_wg_plain > 0 (all slots resident at once): the first n_wg_plain workgroups
+  // take one plain brick each, the others one constrained brick each; n_wg_plain == 0: see below
   template <typename T, int P, int B, int MODE>
   __global__ void
   __launch_bounds__((Geo<P, B>::ABLOCK), 2) lattice_apply_persistent_pair_kernel(const BrickPairArgs<T, P> args)
   {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    if (blockIdx.x < args.n_wg_plain)
+    if (args.n_wg_plain == 0)
+      {
+        // more slots than resident workgroups: EVERY workgroup walks its share of the constrained bricks, then its share
+        // of the plain ones (a static split of the workgroups between the two kinds is only balanced for one cost ratio:
+        // measured 1.59 / 1.52 / 1.50 / 1.54 ms per octant p=1 V-cycle for assumed ratios 1.3 / 1.7 / 2.2 / 3.0)
+        ApplyArgs<T, P> a = args.a;
+        a.g               = args.g_constrained;
+        a.stamps          = nullptr;
+        lattice_apply_persistent_body<T, P, B, MODE, true>(a, blockIdx.x, gridDim.x, smem_raw);
+        __syncthreads(); // the lattice of the last constrained brick has been read by every thread
+        lattice_apply_persistent_body<T, P, B, MODE, false>(args.a, blockIdx.x, gridDim.x, smem_raw);
+      }
+    else if (blockIdx.x < args.n_wg_plain)
       lattice_apply_persistent_body<T, P, B, MODE, false>(args.a, blockIdx.x, args.n_wg_plain, smem_raw);
     else
       {

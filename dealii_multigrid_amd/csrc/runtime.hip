@@ -726,16 +726,12 @@ namespace mgamd
       if constexpr (G::SPW == 1 && G::N_INT > 0 && G::ROUNDS > 1)
         if (use_persistent<T, P>())
           {
-            // resident workgroups split by work (a constrained brick costs ~1.3 plain ones), both parts multiples of 8
-            const int    resident = resident_workgroups(ctx);
-            const double wp = (double)pa.n_wg_plain, wc = 1.3 * (double)n_wg_c;
-            uint32_t     np = pa.n_wg_plain, nc = n_wg_c;
+            const int resident = resident_workgroups(ctx);
+            uint32_t  np = pa.n_wg_plain, nc = n_wg_c;
             if ((int)(np + nc) > resident)
-              {
-                nc = std::min<uint32_t>(n_wg_c, std::max<uint32_t>(8, (uint32_t)std::lround(resident * wc / (wp + wc) / 8.0) * 8));
-                np = std::min<uint32_t>(pa.n_wg_plain, std::max<uint32_t>(8, ((uint32_t)resident - nc) / 8 * 8));
-                if (nc < n_wg_c)
-                  nc = nc / 8 * 8 ? nc / 8 * 8 : 8;
+              { // every workgroup walks both kinds (kernels.hpp)
+                np = 0;
+                nc = (uint32_t)resident;
               }
             pa.n_wg_plain = np;
             auto kern     = lattice_apply_persistent_pair_kernel<T, P, B, MODE>;
