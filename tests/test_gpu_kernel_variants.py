@@ -1,0 +1,32 @@
+"""The 17^3-lattice kernels exist in two forms (persistent workgroups with a software pipeline = default; one workgroup per
+brick = MGAMD_NO_PERSISTENT=1), and tail_kernel reads D^-1 either through one-byte codes (default) or from the vector
+(MGAMD_NO_DINV_CODES=1).  Every other GPU test runs the defaults; here the alternatives are checked against them on meshes
+with several 17^3 bricks (the switches are read when the library is loaded, hence child processes)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CASES = [("quadrant", 7, 4), ("hypercube", 8, 1), ("hypercube", 4, 2)]  # the first two: several bricks per persistent workgroup
+
+
+def run(geo, L, p, out, env_extra):
+    env = dict(os.environ)
+    env.update(env_extra)
+    subprocess.run([sys.executable, os.path.join(HERE, "_vcycle_dump.py"), geo, str(L), str(p), out], check=True, env=env, timeout=600)
+    return np.load(out)
+
+
+@pytest.mark.parametrize("geo,L,p", CASES)
+def test_alternative_kernel_paths_agree(tmp_path, geo, L, p):
+    ref = run(geo, L, p, str(tmp_path / "default.npz"), {})
+    assert any(g[1] > 1 and p * g[0] + 1 == 17 for g in ref["groups"]), "the case must contain several 17^3-lattice bricks"
+    alt = run(geo, L, p, str(tmp_path / "alt.npz"), {"MGAMD_NO_PERSISTENT": "1", "MGAMD_NO_DINV_CODES": "1"})
+    for key in ("ax", "step", "vcycle"):
+        a, b = ref[key], alt[key]
+        assert np.linalg.norm(a - b) <= 1e-12 * np.linalg.norm(a), key
