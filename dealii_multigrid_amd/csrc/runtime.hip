@@ -1681,13 +1681,8 @@ namespace mgamd
       const size_t lds = (size_t)G::LDS * sizeof(T);
       if (prolongate)
         {
-          auto        kern = brick_prolongate_kernel<T, P, B>;
-          static bool once = false;
-          if (!once)
-            {
-              HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-              once = true;
-            }
+          auto kern = brick_prolongate_kernel<T, P, B>;
+          ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), lds);
           hipLaunchKernelGGL(kern, (int)b.n_bricks, G::BLOCK, lds, ctx->stream, a);
         }
       else if (G::NF == 17 && getenv("MGAMD_NO_PERSISTENT") == nullptr)
@@ -1703,13 +1698,8 @@ namespace mgamd
         }
       else
         {
-          auto        kern = brick_restrict_kernel<T, P, B>;
-          static bool once = false;
-          if (!once)
-            {
-              HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-              once = true;
-            }
+          auto kern = brick_restrict_kernel<T, P, B>;
+          ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), lds);
           hipLaunchKernelGGL(kern, (int)b.n_bricks, G::BLOCK, lds, ctx->stream, a);
         }
       HIP_CHECK(hipGetLastError());
