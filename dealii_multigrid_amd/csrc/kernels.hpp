@@ -1496,11 +1496,17 @@ namespace mgamd
       slot = xcd_contiguous(v, n);
       base = args.g.interior_base[slot];
       h    = args.g.h[slot];
+      // (uniform base + round offset in scalar registers, ONE lane offset for every round: per-round lane offsets cost a VGPR
+      // each, were spilled in the 5-word Chebyshev mode and reloaded here behind `s_waitcnt vmcnt(0)` - four exposed memory
+      // round trips per slot)
+      const uint32_t *__restrict__ p0 = args.g.shell_idx + (size_t)slot * G::N_SHELL;
 #pragma unroll
       for (int it = 0; it < ITERS; ++it)
         {
-          const int idx = tid + it * BLOCK;
-          sg[it]        = NT_LOAD(&args.g.shell_idx[(size_t)slot * G::N_SHELL + (idx < G::N_SHELL ? idx : 0)]);
+          if ((it + 1) * BLOCK <= G::N_SHELL)
+            sg[it] = NT_LOAD(p0 + it * BLOCK + tid);
+          else
+            sg[it] = NT_LOAD(p0 + min(tid + it * BLOCK, G::N_SHELL - 1));
         }
     };
     // operator input on the lattice of a slot (x_from_b: b and, on the shell, D^-1)
