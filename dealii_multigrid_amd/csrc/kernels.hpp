@@ -917,7 +917,7 @@ namespace mgamd
   template <typename T, int P, int B, int BLOCK>
   __device__ __forceinline__ void
   brick_constraint_passes(T *__restrict__ buf, const Mats<P> &m, int tid, int nslots, const uint32_t *__restrict__ fmask, bool transpose,
-                          const uint32_t *fm_mine = nullptr) // fm_mine: the mask of this thread's (only) line, already in a register
+                          const uint32_t *fm_mine = nullptr) // fm_mine: the mask of this thread's line(s), already in a register
   {
     using G               = Geo<P, B>;
     constexpr int N       = G::N;
@@ -933,8 +933,8 @@ namespace mgamd
     for (int r = 0; r < ROUNDS; ++r)
       {
         const int l = tid + r * BLOCK, sl = l / G::LINES;
-        if (ROUNDS == 1 && fm_mine != nullptr)
-          fmr[r] = *fm_mine;
+        if (fm_mine != nullptr) // every line of this thread lies in ONE slot (one line per thread, or one slot per workgroup)
+          fmr[r] = (l < TOT && sl < nslots) ? *fm_mine : 0u;
         else
           fmr[r] = (l < TOT && sl < nslots && fmask != nullptr) ? fmask[sl] : 0u;
       }
@@ -1492,10 +1492,14 @@ namespace mgamd
 #define MGAMD_PERSISTENT_STREAMED 1
 #endif
     // slot tables of virtual block v
-    auto load_tables = [&](uint32_t v, uint32_t &slot, uint32_t &base, uint32_t(&sg)[ITERS], double &h) {
+    auto load_tables = [&](uint32_t v, uint32_t &slot, uint32_t &base, uint32_t(&sg)[ITERS], double &h, uint32_t &fm) {
       slot = xcd_contiguous(v, n);
       base = args.g.interior_base[slot];
       h    = args.g.h[slot];
+      fm   = 0;
+      if constexpr (brick_may_be_constrained(B, CONSTR)) // the constraint mask travels with the tables (it was three exposed
+        if (args.g.fmask != nullptr)                     // memory round trips per constrained brick when loaded where used)
+          fm = args.g.fmask[slot];
       // (uniform base + round offset in scalar registers, ONE lane offset for every round: per-round lane offsets cost a VGPR
       // each, were spilled in the 5-word Chebyshev mode and reloaded here behind `s_waitcnt vmcnt(0)` - four exposed memory
       // round trips per slot)
@@ -1525,10 +1529,10 @@ namespace mgamd
         }
     };
 
-    uint32_t slot, base, sgi[ITERS];
+    uint32_t slot, base, sgi[ITERS], fmcur;
     double   hcur;
     T        xg[ITER], sval[ITERS], sb[ITERS];
-    load_tables(w, slot, base, sgi, hcur);
+    load_tables(w, slot, base, sgi, hcur, fmcur);
     load_values(base, sgi, xg, sval, sb);
 
     for (uint32_t v = w;;)
@@ -1568,10 +1572,10 @@ namespace mgamd
               bufA[wk.pos()] = x_from_b ? args.epi.c0 * interior_dinv(wk.type()) * bv[it] : xg[it];
         }
         // ---- slot tables of the next slot, epilogue operands of this one: requested now ------------------------
-        uint32_t slotn = slot, basen = base, sgn[ITERS];
+        uint32_t slotn = slot, basen = base, sgn[ITERS], fmn = fmcur;
         double   hn = hcur;
         if (has_next)
-          load_tables(vn, slotn, basen, sgn, hn);
+          load_tables(vn, slotn, basen, sgn, hn, fmn);
         auto load_operands = [&]() {
 #pragma unroll
           for (int it = 0; it < ITER; ++it)
@@ -1595,12 +1599,9 @@ namespace mgamd
         if constexpr (brick_may_be_constrained(B, CONSTR))
           {
             // constrained bricks: whole-face / whole-edge hanging nodes (uniform branch: one mask per slot)
-            uint32_t fm = 0;
-            if (args.g.fmask != nullptr && tid == 0)
-              fm = args.g.fmask[slot];
-            any_hanging = __syncthreads_or((int)(fm != 0)) != 0;
+            any_hanging = fmcur != 0;
             if (any_hanging)
-              brick_constraint_passes<T, P, B, BLOCK>(bufA, args.m, tid, 1, args.g.fmask + slot, false);
+              brick_constraint_passes<T, P, B, BLOCK>(bufA, args.m, tid, 1, args.g.fmask + slot, false, &fmcur);
           }
         auto mid_hook = [&]() {
           if (!EARLY_OPERANDS && MID_OPERANDS)
@@ -1612,7 +1613,7 @@ namespace mgamd
           lattice_sweeps<T, P, B, BLOCK, decltype(mid_hook), MGAMD_PERSISTENT_STREAMED != 0, MODE != MODE_CHEB>(bufA, bufB, args.m, tid, 1, &hcur, mid_hook);
         if constexpr (brick_may_be_constrained(B, CONSTR))
           if (any_hanging)
-            brick_constraint_passes<T, P, B, BLOCK>(bufA, args.m, tid, 1, args.g.fmask + slot, true);
+            brick_constraint_passes<T, P, B, BLOCK>(bufA, args.m, tid, 1, args.g.fmask + slot, true, &fmcur);
         MGAMD_STAMP(2)
 
         // ---- values of the next slot: requested now, consumed at the top of the next iteration ------------------
@@ -1654,9 +1655,10 @@ namespace mgamd
         if (!has_next)
           break;
         v    = vn;
-        slot = slotn;
-        base = basen;
-        hcur = hn;
+        slot  = slotn;
+        base  = basen;
+        hcur  = hn;
+        fmcur = fmn;
 #pragma unroll
         for (int it = 0; it < ITERS; ++it)
           {
