@@ -16,6 +16,15 @@ $(LIBDIR)/runtime.o: $(CSRC)/runtime.hip $(HDRS)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
+# the operator kernels: one translation unit per (number type, degree), see csrc/apply_inst.hip
+APPLY_OBJS := $(foreach t,f64 f32,$(foreach p,1 2 3 4,$(LIBDIR)/apply_$(t)_p$(p).o))
+$(LIBDIR)/apply_f64_p%.o: $(CSRC)/apply_inst.hip $(HDRS)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -DMGAMD_INST_T=double -DMGAMD_INST_P=$* -c $< -o $@
+$(LIBDIR)/apply_f32_p%.o: $(CSRC)/apply_inst.hip $(HDRS)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -DMGAMD_INST_T=float -DMGAMD_INST_P=$* -c $< -o $@
+
 $(LIBDIR)/c_api_device.o: $(CSRC)/c_api_device.hip $(HDRS)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -24,7 +33,7 @@ $(LIBDIR)/c_api_host.o: $(CSRC)/c_api_host.cpp $(HDRS)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
 
-$(LIB): $(LIBDIR)/runtime.o $(LIBDIR)/c_api_device.o $(LIBDIR)/c_api_host.o
+$(LIB): $(LIBDIR)/runtime.o $(APPLY_OBJS) $(LIBDIR)/c_api_device.o $(LIBDIR)/c_api_host.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -L/opt/rocm/lib -lrccl
 
 $(BIN): dealii_multigrid_amd/harness/multigrid_throughput.cpp $(CSRC)/mgamd.hpp include/mgamd.h $(LIB)

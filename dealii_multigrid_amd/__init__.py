@@ -212,13 +212,6 @@ class DoFs:
     def groups(self):
         return [(self.info.group_B[g], self.info.group_slots[g]) for g in range(self.info.n_groups)]
 
-    def pipeline(self):
-        """(group, chunk_slot_end, tail_stage_end) of the pipelined operator pass; group = -1: not pipelined"""
-        g, n = C.c_int(), C.c_uint32()
-        ce, te = (C.c_uint32 * 16)(), (C.c_uint32 * 16)()
-        _chk(_lib.mgamd_dofs_pipeline(self._h, C.byref(g), C.byref(n), ce, te))
-        return g.value, list(ce[: n.value]), list(te[: n.value])
-
     def cell_slots(self):
         grp, slot = np.zeros(self.info.n_cells, np.uint8), np.zeros(self.info.n_cells, np.uint32)
         _chk(_lib.mgamd_dofs_get_cell_slots(self._h, _ptr(grp), _ptr(slot)))

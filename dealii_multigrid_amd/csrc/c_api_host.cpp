@@ -212,29 +212,6 @@ mgamd_ls_copy_indices(const mgamd_dofs *active_mesh_dofs, const mgamd_dofs *leve
 }
 
 int
-mgamd_dofs_pipeline(const mgamd_dofs *d, int *group, uint32_t *n_chunks, uint32_t *chunk_slot_end, uint32_t *tail_stage_end)
-{
-  MGAMD_TRY
-  if (!d)
-    throw std::invalid_argument("null argument");
-  const LevelTables &L = *d->tables;
-  if (L.chunk_slot_end.size() > 16)
-    throw std::runtime_error("more than 16 pipeline chunks");
-  if (group)
-    *group = L.pipeline_group;
-  if (n_chunks)
-    *n_chunks = (uint32_t)L.chunk_slot_end.size();
-  for (size_t c = 0; c < L.chunk_slot_end.size(); ++c)
-    {
-      if (chunk_slot_end)
-        chunk_slot_end[c] = L.chunk_slot_end[c];
-      if (tail_stage_end)
-        tail_stage_end[c] = L.tail_stage_end[c];
-    }
-  MGAMD_CATCH
-}
-
-int
 mgamd_dofs_get_cell_slots(const mgamd_dofs *d, uint8_t *group, uint32_t *slot)
 {
   MGAMD_TRY

@@ -676,169 +676,6 @@ namespace mgamd
     __syncthreads();
   }
 
-  // ---- WIDE sweeps: 512 threads on one 17-point lattice (4 waves per SIMD with two workgroups per CU instead of 2).
-  // A sweep is 512 half-line tasks (lines 0..255, nodes 8 s .. 8 s + 7 (+ 16), s = tid & 1: the two halves of a line in
-  // adjacent lanes) followed by 132 quarter-line tasks for the 33 left-over lines (as in lattice_sweeps).  A task of SEGN
-  // nodes reads, UP FRONT, the P nodes of the cell to its left (whose last row acts on its first node) and the node to its
-  // right (owned, and overwritten early, by the next task of the line); all tasks of a line sit in one wavefront and run in
-  // lock step, so every lane has these before any lane stores (seg_fence).  Its own nodes are streamed cell by cell.
-  // KIND as in line_stream.  A, Bb point at the task's first node.
-  template <typename T, int P, int KIND, int SEGN>
-  __device__ __forceinline__ void
-  seg_task(const Mats<P> &m, T *__restrict__ A, T *__restrict__ Bb, const int stride, const bool has_left, const bool is_last,
-           const T scale)
-  {
-    static_assert(SEGN % P == 0, "segment = whole cells");
-    constexpr int n = P + 1, CPS = SEGN / P;
-    T             la[n], lb[n];
-#pragma unroll
-    for (int j = 0; j < P; ++j)
-      {
-        la[j] = has_left ? A[(j - P) * stride] : T(0);
-        lb[j] = (KIND != 0 && has_left) ? Bb[(j - P) * stride] : T(0);
-      }
-    la[P]      = A[0];
-    lb[P]      = KIND != 0 ? Bb[0] : T(0);
-    const T ra = A[SEGN * stride], rb = KIND != 0 ? Bb[SEGN * stride] : T(0);
-    seg_fence();
-    T c1 = T(0), c2 = T(0);
-#pragma unroll
-    for (int j = 0; j <= P; ++j)
-      {
-        const T Mj = T(m.M[P * (P + 1) + j]), Kj = T(m.K[P * (P + 1) + j]);
-        if (KIND != 2)
-          c1 += Mj * la[j];
-        c2 += Kj * la[j];
-        if (KIND != 0)
-          c2 += Mj * lb[j];
-      }
-    if (!has_left)
-      c1 = c2 = T(0);
-    T a[n], b[n];
-    a[0] = la[P];
-    b[0] = lb[P];
-#pragma unroll
-    for (int c = 0; c < CPS; ++c)
-      {
-#pragma unroll
-        for (int j = 1; j < n; ++j)
-          {
-            const bool right = c == CPS - 1 && j == P;
-            a[j]             = right ? ra : A[(c * P + j) * stride];
-            if (KIND != 0)
-              b[j] = right ? rb : Bb[(c * P + j) * stride];
-          }
-        T o1[n], o2[n];
-#pragma unroll
-        for (int i = 0; i < n; ++i)
-          o1[i] = o2[i] = T(0);
-        if constexpr (P < 4)
-          {
-#pragma unroll
-            for (int i = 0; i < n; ++i)
-#pragma unroll
-              for (int j = 0; j < n; ++j)
-                {
-                  if (KIND != 2)
-                    o1[i] += T(m.M[i * n + j]) * a[j];
-                  o2[i] += T(m.K[i * n + j]) * a[j];
-                  if (KIND != 0)
-                    o2[i] += T(m.M[i * n + j]) * b[j];
-                }
-          }
-        else
-          {
-            EvenOdd<T, P> xa, xb, y;
-            xa.split(a);
-            if (KIND != 0)
-              xb.split(b);
-            if (KIND != 2)
-              {
-                y.template apply<false>(m.Me, m.Mo, xa);
-                y.add_to(o1);
-              }
-            y.template apply<false>(m.Ke, m.Ko, xa);
-            if (KIND != 0)
-              y.template apply<true>(m.Me, m.Mo, xb);
-            y.add_to(o2);
-          }
-        o1[0] += c1;
-        o2[0] += c2;
-#pragma unroll
-        for (int j = 0; j < P; ++j)
-          {
-            if (KIND != 2)
-              {
-                A[(c * P + j) * stride]  = o1[j];
-                Bb[(c * P + j) * stride] = o2[j];
-              }
-            else
-              A[(c * P + j) * stride] = scale * o2[j];
-          }
-        c1   = o1[P];
-        c2   = o2[P];
-        a[0] = a[P];
-        b[0] = b[P];
-      }
-    if (is_last)
-      {
-        if (KIND != 2)
-          {
-            A[SEGN * stride]  = c1;
-            Bb[SEGN * stride] = c2;
-          }
-        else
-          A[SEGN * stride] = scale * c2;
-      }
-  }
-
-  // the three sweeps of ONE 17-point lattice with 512 threads; ends with a barrier
-  template <typename T, int P, typename Hook = NoHook>
-  __device__ __forceinline__ void
-  lattice_sweeps_wide(T *__restrict__ bufA, T *__restrict__ bufB, const Mats<P> &m, const int tid, const T h, const Hook &before_x = Hook())
-  {
-    static_assert(16 % P == 0 && 8 % P == 0 && 4 % P == 0, "17-point lattices: P in {1, 2, 4}");
-    constexpr int N = 17;
-    // half-line task: line tid / 2, half tid % 2;  quarter-line task (tid < 132): line 256 + tid / 4, quarter tid % 4
-    const int  hl = tid >> 1, hs = tid & 1, hu = hl % N, hv = hl / N;
-    const int  ql = 256 + (tid >> 2), qs = tid & 3, qu = ql % N, qv = ql / N;
-    const bool qt = tid < 4 * (N * N - 256);
-    // z sweep: line (x = u, y = v), stride N^2
-    {
-      const int base = hv * N + hu + 8 * hs * N * N;
-      seg_task<T, P, 0, 8>(m, bufA + base, bufB + base, N * N, hs > 0, hs == 1, T(1));
-      if (qt)
-        {
-          const int b2 = qv * N + qu + 4 * qs * N * N;
-          seg_task<T, P, 0, 4>(m, bufA + b2, bufB + b2, N * N, qs > 0, qs == 3, T(1));
-        }
-    }
-    __syncthreads();
-    // y sweep: line (x = u, z = v), stride N
-    {
-      const int base = hv * N * N + hu + 8 * hs * N;
-      seg_task<T, P, 1, 8>(m, bufA + base, bufB + base, N, hs > 0, hs == 1, T(1));
-      if (qt)
-        {
-          const int b2 = qv * N * N + qu + 4 * qs * N;
-          seg_task<T, P, 1, 4>(m, bufA + b2, bufB + b2, N, qs > 0, qs == 3, T(1));
-        }
-    }
-    __syncthreads();
-    before_x();
-    // x sweep: line (y = u, z = v), stride 1
-    {
-      const int base = (hv * N + hu) * N + 8 * hs;
-      seg_task<T, P, 2, 8>(m, bufA + base, bufB + base, 1, hs > 0, hs == 1, h);
-      if (qt)
-        {
-          const int b2 = (qv * N + qu) * N + 4 * qs;
-          seg_task<T, P, 2, 4>(m, bufA + b2, bufB + b2, 1, qs > 0, qs == 3, h);
-        }
-    }
-    __syncthreads();
-  }
-
   // In-cell hanging-node interpolation (transpose = false, before the sweeps) or its transpose
   // (after), for single-cell slots (N = P+1).  One thread per line; only lines on hanging
   // faces/edges do work.  Ends with a barrier.
@@ -1375,7 +1212,7 @@ namespace mgamd
   //     after    the VALUES of v' are requested (the registers of the sweeps are free again), then epilogue + atomics of v
   // so both round trips of the next gather overlap with work of the current slot.  D^-1 of interior DoFs always in closed
   // form (see lattice_apply_body): that is what frees the registers for the second set of gathered values.
-  template <typename T, int P, int B, int MODE, bool CONSTR = false, int BLOCK_ = Geo<P, B>::ABLOCK>
+  template <typename T, int P, int B, int MODE, bool CONSTR = false>
   __device__ __forceinline__ void
   lattice_apply_persistent_body(const ApplyArgs<T, P> &args, const uint32_t w, const uint32_t stride, unsigned char *smem_raw)
   {
@@ -1386,9 +1223,7 @@ namespace mgamd
     T *bufB = bufA + G::N3;
     T *dtab = bufB + G::N3; // [P^3] s = d/h, [P^3] 1/s
 
-    constexpr int  BLOCK = BLOCK_;
-    constexpr bool WIDE  = BLOCK == 512; // 512 threads: half-line sweeps (lattice_sweeps_wide), <= 128 VGPRs
-    static_assert(BLOCK == G::ABLOCK || (WIDE && G::N == 17 && !CONSTR), "block size");
+    constexpr int BLOCK = G::ABLOCK;
     constexpr int ITER  = (G::N_INT + BLOCK - 1) / BLOCK;
     constexpr int ITERS = (G::N_SHELL + BLOCK - 1) / BLOCK;
     constexpr int P3    = P * P * P;
@@ -1477,20 +1312,10 @@ namespace mgamd
     __syncthreads();
 
     constexpr bool x_from_b = MODE == MODE_CHEB_FIRST; // x = c0 dinv b, never stored
-    // the epilogue operands (x_old, b) of a slot: requested before its sweeps (their latency hides behind the arithmetic, but
-    // they are live across the sweeps: with the second set of gathered values the Chebyshev modes then exceed 256 VGPRs), or
-    // after them, ahead of the next slot's values
-#ifndef MGAMD_PERSISTENT_EARLY_OPERANDS
-#define MGAMD_PERSISTENT_EARLY_OPERANDS 1
-#endif
-    constexpr bool EARLY_OPERANDS = MGAMD_PERSISTENT_EARLY_OPERANDS || !(MODE == MODE_CHEB || MODE == MODE_CHEB_SECOND);
-#ifndef MGAMD_PERSISTENT_MID_OPERANDS
-#define MGAMD_PERSISTENT_MID_OPERANDS 0
-#endif
-    constexpr bool MID_OPERANDS = MGAMD_PERSISTENT_MID_OPERANDS; // between the y and the x sweep
-#ifndef MGAMD_PERSISTENT_STREAMED
-#define MGAMD_PERSISTENT_STREAMED 1
-#endif
+    // the epilogue operands (x_old, b) of a slot are requested BEFORE its sweeps (their latency hides behind the arithmetic);
+    // they are live across the sweeps, which is why the sweeps are streamed cell by cell (line_stream: ~35 instead of ~70
+    // doubles per thread).  Requested after the sweeps, or between the y and the x sweep, they fit whole-line sweeps but expose
+    // their latency (measured: no gain over the one-workgroup-per-brick kernel).
     // slot tables of virtual block v
     auto load_tables = [&](uint32_t v, uint32_t &slot, uint32_t &base, uint32_t(&sg)[ITERS], double &h, uint32_t &fm) {
       slot = xcd_contiguous(v, n);
@@ -1576,7 +1401,7 @@ namespace mgamd
         double   hn = hcur;
         if (has_next)
           load_tables(vn, slotn, basen, sgn, hn, fmn);
-        auto load_operands = [&]() {
+        {
 #pragma unroll
           for (int it = 0; it < ITER; ++it)
             {
@@ -1589,9 +1414,7 @@ namespace mgamd
               if ((MODE == MODE_RESIDUAL || is_cheb(MODE)) && !x_from_b)
                 bv[it] = NT_LOAD(&args.epi.b[g]);
             }
-        };
-        if (EARLY_OPERANDS)
-          load_operands();
+        }
         __syncthreads();
         MGAMD_STAMP(1)
 
@@ -1603,22 +1426,14 @@ namespace mgamd
             if (any_hanging)
               brick_constraint_passes<T, P, B, BLOCK>(bufA, args.m, tid, 1, args.g.fmask + slot, false, &fmcur);
           }
-        auto mid_hook = [&]() {
-          if (!EARLY_OPERANDS && MID_OPERANDS)
-            load_operands();
-        };
-        if constexpr (WIDE)
-          lattice_sweeps_wide<T, P>(bufA, bufB, args.m, tid, T(hcur), mid_hook);
-        else
-          lattice_sweeps<T, P, B, BLOCK, decltype(mid_hook), MGAMD_PERSISTENT_STREAMED != 0, MODE != MODE_CHEB>(bufA, bufB, args.m, tid, 1, &hcur, mid_hook);
+        // cell prefetch in the streamed sweeps (-4 % on the 2-4-word passes); the 5-word mode has no registers left for it
+        lattice_sweeps<T, P, B, BLOCK, NoHook, true, MODE != MODE_CHEB>(bufA, bufB, args.m, tid, 1, &hcur);
         if constexpr (brick_may_be_constrained(B, CONSTR))
           if (any_hanging)
             brick_constraint_passes<T, P, B, BLOCK>(bufA, args.m, tid, 1, args.g.fmask + slot, true, &fmcur);
         MGAMD_STAMP(2)
 
         // ---- values of the next slot: requested now, consumed at the top of the next iteration ------------------
-        if (!EARLY_OPERANDS && !MID_OPERANDS)
-          load_operands();
         T xgn[ITER], svaln[ITERS], sbn[ITERS];
         if (has_next)
           load_values(basen, sgn, xgn, svaln, sbn);
@@ -1718,9 +1533,8 @@ namespace mgamd
       }
   }
 
-  // (A 512-thread instantiation of the body with lattice_sweeps_wide - 4 waves per SIMD, <= 128 VGPRs - was measured on MI355X:
-  // the sweeps alone are 19 % faster (tools/sweep_probe.hip), the kernel is not: vmult 950 -> 964 us per pass, and the
-  // Chebyshev modes spill (6.2 instead of 4.4 ms per step()); BLOCK_ = 512 still compiles for such experiments.)
+  // (A 512-thread variant with half-line sweep tasks - 4 waves per SIMD, <= 128 VGPRs - was measured on MI355X: the sweeps alone
+  // are 19 % faster (tools/sweep_probe.hip), the kernel is not: vmult 950 -> 964 us per pass, and the Chebyshev modes spill.)
   // the pair launch with persistent workgroups.  n_wg_plain > 0 (all slots resident at once): the first n_wg_plain workgroups
   // take one plain brick each, the others one constrained brick each; n_wg_plain == 0: see below
   template <typename T, int P, int B, int MODE>
@@ -3306,6 +3120,7 @@ namespace mgamd
       partial[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
   }
 
+  template <typename = void> // (a template only so that the header can be included by several translation units)
   __global__ void
   __launch_bounds__(256) vec_dot_final_kernel(const double *__restrict__ partial, int n, double *__restrict__ result)
   {

@@ -369,14 +369,6 @@ namespace mgamd
     static constexpr uint32_t CLS_MASK  = (1u << CLS_SHIFT) - 1;
     // distributed runs: the tail is [owned | copies of DoFs owned by a lower rank]; *_owned count each DoF once globally
     uint32_t n_tail_owned = 0, n_dirichlet_owned = 0, n_hanging_owned = 0;
-    // Pipelined operator pass (runtime.hip): the slots of the group with the most work
-    // (pipeline_group) are launched in n_chunks Morton-contiguous chunks [chunk_slot_end[c-1], chunk_slot_end[c]); the owned
-    // tail is ordered by COMPLETION STAGE: a tail DoF whose touching slots all belong to chunks <= c of that group sits in
-    // [tail_stage_end[c-1], tail_stage_end[c]) and its epilogue can run as soon as chunk c has finished, overlapping with
-    // the later chunks; everything else (DoFs touched by another group, DoFs shared with other ranks) is in the final stage
-    // [tail_stage_end[n_chunks-1], n_tail).  n_chunks = 0: no pipelining (one stage).
-    int                   pipeline_group = -1;
-    std::vector<uint32_t> chunk_slot_end, tail_stage_end;
     // per cell: group, slot-in-group
     std::vector<uint8_t>  cell_group;
     std::vector<uint32_t> cell_slot;
@@ -1071,70 +1063,6 @@ namespace mgamd
                         classify(key, 2);
                     }
                 }
-      // ---- 3b. completion stages of the owned tail (pipelined operator pass)
-      std::vector<uint32_t> tail_perm; // provisional owned-tail counter -> position in the staged order
-      {
-        // OFF by default: measured on MI355X (octant p=4 L=8: 11.56 vs 11.12 ms per V-cycle, p=1 L=9: 2.26 vs 1.91 ms) the
-        // two-queue pass is slower than the plain one -- the Chebyshev passes are bound by HBM bytes, which overlap does not
-        // reduce, and every chunk boundary costs a cross-queue dependency.  MGAMD_PIPELINE=1 enables it.
-        const char *on        = getenv("MGAMD_PIPELINE");
-        size_t      min_slots = 2048; // fewer bricks than this are a few rounds of workgroups: nothing to overlap
-        int         want      = (on && atoi(on)) ? 4 : 0;
-        if (const char *e = getenv("MGAMD_PIPELINE_MIN_SLOTS"))
-          min_slots = (size_t)atol(e);
-        if (const char *e = getenv("MGAMD_PIPELINE_CHUNKS"))
-          want = atoi(e);
-        size_t best = 0;
-        for (size_t gi = 0; gi < groups.size(); ++gi)
-          {
-            const size_t work = groups[gi].n_slots() * (size_t)groups[gi].N * groups[gi].N * groups[gi].N;
-            if (groups[gi].B > 1 && work > best)
-              {
-                best           = work;
-                pipeline_group = (int)gi;
-              }
-          }
-        const size_t nbig = pipeline_group >= 0 ? groups[pipeline_group].n_slots() : 0;
-        if (want < 1 || nbig < min_slots || nbig < (size_t)want)
-          pipeline_group = -1;
-        else
-          {
-            const uint32_t C = (uint32_t)want;
-            chunk_slot_end.resize(C);
-            for (uint32_t c = 0; c < C; ++c)
-              chunk_slot_end[c] = (uint32_t)(((uint64_t)nbig * (c + 1)) / C);
-            std::vector<uint8_t> stage(counter[0], 0);
-            for (const Ref &r : order)
-              {
-                const SlotGroup &g = groups[r.group];
-                uint8_t          st = (uint8_t)C;
-                if ((int)r.group == pipeline_group)
-                  st = (uint8_t)(std::upper_bound(chunk_slot_end.begin(), chunk_slot_end.end(), r.slot) - chunk_slot_end.begin());
-                for (int s = 0; s < g.n_shell; ++s)
-                  {
-                    const uint32_t v = g.shell_idx[(size_t)r.slot * g.n_shell + s];
-                    if (v != INVALID_DOF && (v >> CLS_SHIFT) == 0)
-                      stage[v & CLS_MASK] = std::max(stage[v & CLS_MASK], st);
-                  }
-              }
-            if (shared) // the partial sums of DoFs on inter-rank interfaces are completed by the halo exchange first
-              for (size_t t = 0; t < key_list.size(); ++t)
-                {
-                  const uint32_t v = (uint32_t)*keymap.find(key_list[t]);
-                  if ((v >> CLS_SHIFT) == 0 && shared->find(key_list[t]) != shared->end())
-                    stage[v & CLS_MASK] = (uint8_t)C;
-                }
-            std::vector<uint32_t> count(C + 2, 0);
-            for (uint8_t st : stage)
-              ++count[st + 1];
-            for (uint32_t c = 0; c <= C; ++c)
-              count[c + 1] += count[c];
-            tail_stage_end.assign(count.begin() + 1, count.begin() + 1 + C);
-            tail_perm.resize(counter[0]);
-            for (uint32_t i = 0; i < counter[0]; ++i) // stable: first-touch order is kept inside a stage
-              tail_perm[i] = count[stage[i]]++;
-          }
-      }
       n_tail_owned      = counter[0];
       n_tail            = counter[0] + counter[3];
       n_dirichlet       = counter[1];
@@ -1150,7 +1078,7 @@ namespace mgamd
                                 n_interior + n_tail};
       auto           final_index = [&](uint32_t prov) {
         const uint32_t c = prov & CLS_MASK;
-        return base[prov >> CLS_SHIFT] + (((prov >> CLS_SHIFT) == 0 && !tail_perm.empty()) ? tail_perm[c] : c);
+        return base[prov >> CLS_SHIFT] + c;
       };
       key_index.resize(key_list.size());
       for (size_t t = 0; t < key_list.size(); ++t)

@@ -1,6 +1,6 @@
 // Device runtime implementation (see runtime.hpp).  Compiled with hipcc --offload-arch=gfx950.
 #include "runtime.hpp"
-#include "kernels.hpp"
+#include "level_operator.hpp"
 
 #include <chrono>
 #include <cmath>
@@ -74,16 +74,6 @@ namespace mgamd
     prof_used = 0;
   }
 
-  static inline int
-  grid_for(size_t n)
-  {
-    size_t g = (n + 255) / 256;
-    if (g > 2048)
-      g = 2048;
-    if (g < 1)
-      g = 1;
-    return (int)g;
-  }
 } // namespace mgamd
 
 mgamd_vec::~mgamd_vec()
@@ -155,21 +145,6 @@ namespace mgamd
                          y.n);
   }
 
-  template <typename T>
-  static double
-  dot_raw(Ctx *ctx, const T *x, const T *y, size_t n)
-  {
-    if (!n)
-      return 0.0;
-    int g = grid_for(n);
-    if (g > 1024)
-      g = 1024;
-    hipLaunchKernelGGL(vec_dot_kernel<T>, g, 256, 0, ctx->stream, x, y, n, ctx->d_partial);
-    hipLaunchKernelGGL(vec_dot_final_kernel, 1, 256, 0, ctx->stream, ctx->d_partial, g, ctx->d_result);
-    HIP_CHECK(hipMemcpyAsync(ctx->h_result, ctx->d_result, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    ctx->sync();
-    return ctx->h_result[0];
-  }
 
   // S[slot] = x . y over the first n entries, summed over the ranks of `comm` (stream-ordered, no host synchronisation)
   template <typename T>
@@ -178,7 +153,7 @@ namespace mgamd
   {
     int g = std::min(grid_for(std::max<size_t>(n, 1)), 1024);
     hipLaunchKernelGGL(cg_dot_kernel<T>, g, 256, 0, ctx->stream, x, y, n, ctx->d_partial);
-    hipLaunchKernelGGL(vec_dot_final_kernel, 1, 256, 0, ctx->stream, ctx->d_partial, g, S + slot);
+    hipLaunchKernelGGL(vec_dot_final_kernel<>, 1, 256, 0, ctx->stream, ctx->d_partial, g, S + slot);
     if (comm)
       comm->allreduce_sum(S + slot, 1, MGAMD_F64, ctx->stream);
   }
@@ -219,7 +194,7 @@ namespace mgamd
         vmult(Ap, p);
         dot_to_device(ctx, comm, S, p, Ap, n_dot, 2);
         hipLaunchKernelGGL(cg_update_xr_kernel<T>, gd, 256, 0, ctx->stream, x, r, p, Ap, n, n_dot, S, cur, ctx->d_partial);
-        hipLaunchKernelGGL(vec_dot_final_kernel, 1, 256, 0, ctx->stream, ctx->d_partial, gd, S + 3);
+        hipLaunchKernelGGL(vec_dot_final_kernel<>, 1, 256, 0, ctx->stream, ctx->d_partial, gd, S + 3);
         if (comm)
           comm->allreduce_sum(S + 3, 1, MGAMD_F64, ctx->stream);
         res          = std::sqrt(read_scalar(ctx, S, 3));
@@ -287,899 +262,6 @@ namespace mgamd
     exchange_add_tail(b); // contributions of the other ranks' cells to shared DoFs
     ctx->sync();
   }
-
-  // ------------------------------------------------------------------------------------------
-  // Level operator
-  // ------------------------------------------------------------------------------------------
-  // hipFuncAttributeMaxDynamicSharedMemorySize once per (device, kernel); callers may be concurrent host threads (SimComm)
-  static void
-  ensure_dynamic_lds(Ctx *ctx, const void *kern, size_t lds)
-  {
-    static std::mutex                             m;
-    static std::set<std::pair<int, const void *>> done;
-    std::lock_guard<std::mutex>                   lock(m);
-    if (done.insert({ctx->device, kern}).second)
-      HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  }
-
-  // persistent workgroups for the one-slot-per-workgroup lattices (kernels.hpp, lattice_apply_persistent_body); not for
-  // float at p = 4, whose Chebyshev instantiation spills 35 registers
-  template <typename T, int P>
-  static bool
-  use_persistent()
-  {
-    static const bool on = getenv("MGAMD_NO_PERSISTENT") == nullptr;
-    return on && !(P == 4 && std::is_same<T, float>::value);
-  }
-  // two 4-wave workgroups with a 17^3 lattice pair each fit one CU; a multiple of 8 keeps a workgroup in its XCD's range
-  static int
-  resident_workgroups(const Ctx *ctx)
-  {
-    return std::max(8, 2 * ctx->n_cu / 8 * 8);
-  }
-
-  template <typename T, int P, int B, int MODE, bool CONSTR = false>
-  static void
-  launch_lattice(Ctx *ctx, hipStream_t st, const ApplyArgs<T, P> &a, bool diag)
-  {
-    using G = Geo<P, B>;
-    if (a.g.n_slots == 0)
-      return;
-    const int grid = (int)((a.g.n_slots + G::SPW - 1) / G::SPW);
-    if (diag)
-      {
-        const size_t lds  = 3 * (size_t)G::SPW * G::N3 * sizeof(T);
-        auto         kern = lattice_diag_kernel<T, P, B, CONSTR>;
-        ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), lds);
-        hipLaunchKernelGGL(kern, grid, G::BLOCK, lds, st, a);
-      }
-    else
-      {
-        const size_t lds  = (2 * (size_t)G::SPW * G::N3 + 2 * P * P * P + G::SPW) * sizeof(T);
-        if constexpr (G::SPW == 1 && G::N_INT > 0 && G::ROUNDS > 1)
-          {
-            // one-slot-per-workgroup lattices (17^3): persistent workgroups with a software pipeline over their slots
-            // (kernels.hpp, lattice_apply_persistent_body).  Two workgroups fit a CU (LDS); the grid is a multiple of 8 so
-            // that a workgroup stays inside the Morton range of its XCD.  MGAMD_NO_PERSISTENT=1: one workgroup per slot.
-            if (use_persistent<T, P>())
-              {
-                const int resident = resident_workgroups(ctx);
-                auto      kern     = lattice_apply_persistent_kernel<T, P, B, MODE, CONSTR>;
-                ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), lds);
-                hipLaunchKernelGGL(kern, std::min(grid, resident), G::ABLOCK, lds, st, a);
-                HIP_CHECK(hipGetLastError());
-                return;
-              }
-          }
-        auto         kern = lattice_apply_kernel<T, P, B, MODE, CONSTR>;
-        ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), lds);
-        hipLaunchKernelGGL(kern, grid, G::ABLOCK, lds, st, a);
-      }
-    HIP_CHECK(hipGetLastError());
-  }
-
-  // constrained = the group of constrained bricks larger than a family (p = 1 only, LevelTables::build)
-  template <typename T, int P, int MODE>
-  static void
-  dispatch_B(Ctx *ctx, hipStream_t st, int B, bool constrained, const ApplyArgs<T, P> &a, bool diag)
-  {
-    if (constrained)
-      {
-        if constexpr (P * 4 + 1 <= 17)
-          if (B == 4)
-            return launch_lattice<T, P, 4, MODE, true>(ctx, st, a, diag);
-        if constexpr (P * 8 + 1 <= 17)
-          if (B == 8)
-            return launch_lattice<T, P, 8, MODE, true>(ctx, st, a, diag);
-        if constexpr (P * 16 + 1 <= 17)
-          if (B == 16)
-            return launch_lattice<T, P, 16, MODE, true>(ctx, st, a, diag);
-        throw std::runtime_error("constrained bricks of this size/degree are not instantiated");
-      }
-    switch (B)
-      {
-        case 1:
-          launch_lattice<T, P, 1, MODE>(ctx, st, a, diag);
-          return;
-        case 2:
-          if constexpr (P * 2 + 1 <= 17)
-            {
-              launch_lattice<T, P, 2, MODE>(ctx, st, a, diag);
-              return;
-            }
-          break;
-        case 4:
-          if constexpr (P * 4 + 1 <= 17)
-            {
-              launch_lattice<T, P, 4, MODE>(ctx, st, a, diag);
-              return;
-            }
-          break;
-        case 8:
-          if constexpr (P * 8 + 1 <= 17)
-            {
-              launch_lattice<T, P, 8, MODE>(ctx, st, a, diag);
-              return;
-            }
-          break;
-        case 16:
-          if constexpr (P * 16 + 1 <= 17)
-            {
-              launch_lattice<T, P, 16, MODE>(ctx, st, a, diag);
-              return;
-            }
-          break;
-      }
-    throw std::runtime_error("unsupported brick size");
-  }
-
-  template <typename T>
-  struct GroupDev
-  {
-    int            B = 1, N = 2;
-    bool           constrained = false; // the group of constrained bricks larger than a family
-    size_t         n_halo      = 0;     // sharded levels: the first n_halo slots touch DoFs shared with other ranks
-    size_t         n_slots = 0;
-    DBuf<uint32_t> interior_base, shell_idx;
-    DBuf<uint16_t> mask, shell_pos;
-    DBuf<double>   h;
-    DBuf<uint32_t> fmask; // constrained 2^3 bricks, only if the group has any
-    SlotGroupDev
-    view() const
-    {
-      return SlotGroupDev{interior_base.p, shell_idx.p, mask.p, h.p, shell_pos.p, (uint32_t)n_slots, fmask.p};
-    }
-    // slots [begin, end) only (a chunk of the pipelined pass)
-    SlotGroupDev
-    view(size_t begin, size_t end) const
-    {
-      const size_t n_shell = (size_t)N * N * N - (size_t)(N - 2) * (N - 2) * (N - 2);
-      return SlotGroupDev{interior_base.p + begin, shell_idx.p + begin * n_shell, mask.p + begin, h.p + begin, shell_pos.p,
-                          (uint32_t)(end - begin), fmask.p ? fmask.p + begin : nullptr};
-    }
-    // single cells at p = 1: per-cluster distinct node lists for cell_cluster_apply_kernel
-    DBuf<uint32_t> uniq_ptr, uniq_idx;
-    DBuf<uint16_t> loc;
-    uint32_t       max_uniq = 0;
-    bool
-    has_clusters() const
-    {
-      return uniq_ptr.p != nullptr;
-    }
-    CellClusterDev
-    cluster_view() const
-    {
-      return CellClusterDev{uniq_ptr.p, uniq_idx.p, loc.p, mask.p, h.p, (uint32_t)n_slots, max_uniq};
-    }
-    void
-    build_clusters(const SlotGroup &g)
-    {
-      const size_t          ns = g.n_slots(), ncl = (ns + CLUSTER_CELLS - 1) / CLUSTER_CELLS;
-      std::vector<uint32_t> ptr(ncl + 1, 0), idx;
-      std::vector<uint16_t> l(ns * 8, 0xFFFFu);
-      std::vector<uint32_t> tmp;
-      for (size_t c = 0; c < ncl; ++c)
-        {
-          const size_t s0 = c * CLUSTER_CELLS, s1 = std::min(ns, s0 + CLUSTER_CELLS);
-          tmp.clear();
-          for (size_t sl = s0; sl < s1; ++sl)
-            for (int s = 0; s < 8; ++s)
-              if (g.shell_idx[sl * 8 + s] != INVALID_DOF)
-                tmp.push_back(g.shell_idx[sl * 8 + s]);
-          std::sort(tmp.begin(), tmp.end());
-          tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
-          for (size_t sl = s0; sl < s1; ++sl)
-            for (int s = 0; s < 8; ++s)
-              {
-                const uint32_t gi = g.shell_idx[sl * 8 + s];
-                if (gi != INVALID_DOF)
-                  l[sl * 8 + g.shell_pos[s]] = (uint16_t)(std::lower_bound(tmp.begin(), tmp.end(), gi) - tmp.begin());
-              }
-          idx.insert(idx.end(), tmp.begin(), tmp.end());
-          ptr[c + 1] = (uint32_t)idx.size();
-          max_uniq   = std::max<uint32_t>(max_uniq, (uint32_t)tmp.size());
-        }
-      if (idx.empty())
-        idx.push_back(0);
-      uniq_ptr.upload(ptr);
-      uniq_idx.upload(idx);
-      loc.upload(l);
-    }
-  };
-
-  template <typename T>
-  struct LevelOperator : LevelOperatorBase
-  {
-    int                                       p = 1;
-    std::vector<std::unique_ptr<GroupDev<T>>> groups;
-    DBuf<T>                                   tail_acc;
-    // D^-1 codes of the tail / constrained DoFs for tail_kernel (kernels.hpp, Epilogue::dinv_code), valid for the vector dinv_coded
-    DBuf<uint8_t>                             dinv_code;
-    DBuf<T>                                   dinv_table;
-    const T                                  *dinv_coded = nullptr;
-    int                                       prof_B = 0; // brick size whose CHEB launches are profiled
-    uint32_t                                  ablate = 0; // debug: MGAMD_ABLATE
-    DBuf<unsigned long long>                  stamps;     // debug: MGAMD_STAMPS=<mode>, 8 stamps per workgroup of the largest group
-    int                                       stamp_mode = -1;
-    bool                                      merge_small = true; // MGAMD_NO_MERGE_SMALL=1: separate launches (development A/B)
-    bool                                      halo_overlap = true; // MGAMD_NO_HALO_OVERLAP=1: exchange after all slots, on the main queue
-
-    // sharded runs: device image of the halo plan
-    struct HaloDev
-    {
-      DBuf<uint32_t> pack_idx, sh_tail, sh_ptr;
-      DBuf<int32_t>  sh_src, sh_owner_src;
-      DBuf<T>        send, recv;
-    };
-    std::unique_ptr<HaloDev> halo;
-
-    LevelOperator(Ctx *c, const mgamd_dofs *dofs, std::shared_ptr<Comm> cm)
-    {
-      ctx    = c;
-      type   = (int)sizeof(T);
-      tables = dofs->tables;
-      tria   = dofs->tria;
-      p      = tables->p;
-      if (cm && dofs->halo)
-        {
-          comm      = cm;
-          halo_plan = dofs->halo;
-          halo      = std::make_unique<HaloDev>();
-          halo->pack_idx.upload(halo_plan->pack_idx);
-          halo->sh_tail.upload(halo_plan->sh_tail);
-          halo->sh_ptr.upload(halo_plan->sh_ptr);
-          halo->sh_src.upload(halo_plan->sh_src);
-          halo->sh_owner_src.upload(halo_plan->sh_owner_src);
-          halo->send.alloc(std::max<size_t>(halo_plan->pack_idx.size(), 1));
-          halo->recv.alloc(std::max<size_t>(halo_plan->pack_idx.size(), 1));
-        }
-      if (p > 4)
-        throw std::runtime_error("degrees above 4 are not instantiated in this build");
-      size_t best = 0;
-      for (const SlotGroup &g : tables->groups)
-        {
-          auto d     = std::make_unique<GroupDev<T>>();
-          d->B           = g.B;
-          d->N           = g.N;
-          d->constrained = g.constrained_group;
-          d->n_halo      = g.n_halo_slots;
-          d->n_slots = g.n_slots();
-          if (d->n_slots)
-            {
-              d->interior_base.upload(g.interior_base);
-              d->shell_idx.upload(g.shell_idx);
-              d->mask.upload(g.mask);
-              d->h.upload(g.h);
-              d->shell_pos.upload(g.shell_pos);
-              if (std::any_of(g.fmask.begin(), g.fmask.end(), [](uint32_t m) { return m != 0; }))
-                d->fmask.upload(g.fmask);
-              if (p == 1 && g.B == 1 && !getenv("MGAMD_NO_CELL_CLUSTERS") && !tables->ls_level)
-                d->build_clusters(g); // (the cluster tables bake in which nodes are constrained: not on local-smoothing levels)
-            }
-          const size_t work = d->n_slots * (size_t)g.N * g.N * g.N;
-          if (work > best)
-            {
-              best   = work;
-              prof_B = g.B;
-            }
-          groups.push_back(std::move(d));
-        }
-      if (const char *e = getenv("MGAMD_ABLATE"))
-        ablate = (uint32_t)atoi(e);
-      merge_small = getenv("MGAMD_NO_MERGE_SMALL") == nullptr;
-      halo_overlap = getenv("MGAMD_NO_HALO_OVERLAP") == nullptr;
-      if (const char *e = getenv("MGAMD_STAMPS"))
-        {
-          stamp_mode = atoi(e);
-          size_t nwg = 0;
-          for (auto &g : groups)
-            if (g->B == prof_B)
-              nwg = g->n_slots; // >= number of workgroups
-          stamps.alloc(nwg * 8 + 8);
-          stamps.zero(ctx->stream);
-        }
-      tail_acc.alloc(std::max<uint32_t>(tables->n_tail + tables->n_edge, 1));
-      tail_acc.zero(ctx->stream);
-    }
-
-    // tail[t] <- sum over the sharing ranks (ascending rank order) of their partial tail[t]
-    void
-    exchange_add_raw(T *tail, hipStream_t st = nullptr)
-    {
-      if (!halo)
-        return;
-      if (!st)
-        st = ctx->stream;
-      const uint32_t ns = (uint32_t)halo_plan->pack_idx.size();
-      if (ns)
-        hipLaunchKernelGGL(halo_pack_kernel<T>, grid_for(ns), 256, 0, st, halo->send.p, tail, halo->pack_idx.p, ns);
-      comm->exchange(halo->send.p, halo->recv.p, halo_plan->peers, halo_plan->peer_offset, sizeof(T), st);
-      const uint32_t nsh = (uint32_t)halo_plan->sh_tail.size();
-      if (nsh)
-        hipLaunchKernelGGL(halo_combine_kernel<T>, grid_for(nsh), 256, 0, st, tail, halo->recv.p, halo->sh_tail.p, halo->sh_ptr.p,
-                           halo->sh_src.p, nsh);
-      HIP_CHECK(hipGetLastError());
-    }
-    // tail[t] <- the owner's value, for the copies this rank holds of DoFs owned elsewhere
-    void
-    import_from_owner_raw(T *tail)
-    {
-      if (!halo)
-        return;
-      const uint32_t ns = (uint32_t)halo_plan->pack_idx.size();
-      if (ns)
-        hipLaunchKernelGGL(halo_pack_kernel<T>, grid_for(ns), 256, 0, ctx->stream, halo->send.p, tail, halo->pack_idx.p, ns);
-      comm->exchange(halo->send.p, halo->recv.p, halo_plan->peers, halo_plan->peer_offset, sizeof(T), ctx->stream);
-      const uint32_t nsh = (uint32_t)halo_plan->sh_tail.size();
-      if (nsh)
-        hipLaunchKernelGGL(halo_import_kernel<T>, grid_for(nsh), 256, 0, ctx->stream, tail, halo->recv.p, halo->sh_tail.p,
-                           halo->sh_owner_src.p, nsh);
-      HIP_CHECK(hipGetLastError());
-    }
-    void
-    exchange_add_tail(mgamd_vec &v) override
-    {
-      if (v.n != n_dofs())
-        throw std::invalid_argument("exchange_add_tail: vector size mismatch");
-      exchange_add_raw(v.as<T>() + tables->n_interior);
-    }
-    double
-    dot_raw_global(const T *x, const T *y)
-    {
-      if (!comm)
-        return dot_raw(ctx, x, y, (size_t)n_dofs());
-      // constrained entries are zero in every vector of the sharded solver path (homogeneous data), so the owned
-      // prefix [interior | owned tail] counts every DoF exactly once
-      const double local = dot_raw(ctx, x, y, (size_t)tables->n_interior + tables->n_tail_owned);
-      return comm->allreduce_sum_host(local, ctx->stream);
-    }
-    double
-    dot(const mgamd_vec &x, const mgamd_vec &y) override
-    {
-      if (x.n != n_dofs() || y.n != n_dofs())
-        throw std::invalid_argument("dot: vector size mismatch");
-      return dot_raw_global(x.as<T>(), y.as<T>());
-    }
-
-    template <int P>
-    Mats<P>
-    mats() const
-    {
-      Mats<P>   m;
-      const int n = P + 1;
-      for (int i = 0; i < n * n; ++i)
-        {
-          m.M[i]  = tables->fe.M[i];
-          m.K[i]  = tables->fe.K[i];
-          m.I0[i] = tables->fe.I[0][i];
-          m.I1[i] = tables->fe.I[1][i];
-        }
-      constexpr int NH = Mats<P>::NH, NO = Mats<P>::NO;
-      auto          eo = [&](const double *A, double *Ae, double *Ao) {
-        for (int i = 0; i < NH; ++i)
-          for (int j = 0; j < NH; ++j)
-            Ae[i * NH + j] = (j < NO) ? 0.5 * (A[i * n + j] + A[i * n + P - j]) : A[i * n + j];
-        for (int i = 0; i < NO; ++i)
-          for (int j = 0; j < NO; ++j)
-            Ao[i * NO + j] = 0.5 * (A[i * n + j] - A[i * n + P - j]);
-      };
-      eo(m.M, m.Me, m.Mo);
-      eo(m.K, m.Ke, m.Ko);
-      return m;
-    }
-
-    ClusterArgs<T>
-    cluster_args(const GroupDev<T> &g, const T *src, const Epilogue<T> &epi, bool first)
-    {
-      ClusterArgs<T> a;
-      a.c          = g.cluster_view();
-      a.m          = mats<1>();
-      a.src        = src;
-      a.tail_acc   = tail_acc.p;
-      a.n_interior = tables->n_interior;
-      a.b          = epi.b;
-      a.dinv       = epi.dinv;
-      a.c0         = epi.c0;
-      a.from_b     = first ? 1 : 0;
-      a.cluster_offset = 0;
-      return a;
-    }
-
-    void
-    launch_clusters(hipStream_t st, const GroupDev<T> &g, const T *src, const Epilogue<T> &epi, bool first, uint32_t cluster_begin = 0,
-                    uint32_t cluster_end = 0xFFFFFFFFu)
-    {
-      ClusterArgs<T> a;
-      a.c          = g.cluster_view();
-      a.m          = mats<1>();
-      a.src        = src;
-      a.tail_acc   = tail_acc.p;
-      a.n_interior = tables->n_interior;
-      a.b          = epi.b;
-      a.dinv       = epi.dinv;
-      a.c0         = epi.c0;
-      a.from_b     = first ? 1 : 0;
-      a.cluster_offset = 0;
-      const uint32_t n_cl = (uint32_t)((g.n_slots + CLUSTER_CELLS - 1) / CLUSTER_CELLS);
-      cluster_end         = std::min(cluster_end, n_cl);
-      if (cluster_begin >= cluster_end)
-        return;
-      a.cluster_offset    = cluster_begin;
-      const uint32_t grid = cluster_end - cluster_begin;
-      hipLaunchKernelGGL(cell_cluster_apply_kernel<T>, grid, CLUSTER_CELLS, 2 * (size_t)std::max<uint32_t>(g.max_uniq, 1) * sizeof(T), st, a);
-      HIP_CHECK(hipGetLastError());
-    }
-
-    // launches of one slot group (with its merge partner, if any) on stream st; [begin, end) restricts an unmerged group
-    // to a slot range
-    template <int P, int B, int MODE>
-    void
-    launch_pair(hipStream_t st, const ApplyArgs<T, P> &a, GroupDev<T> *g_constrained)
-    {
-      using G = Geo<P, B>;
-      BrickPairArgs<T, P> pa;
-      pa.a             = a;
-      pa.g_constrained = g_constrained->view();
-      pa.n_wg_plain    = (uint32_t)((a.g.n_slots + G::SPW - 1) / G::SPW);
-      const uint32_t n_wg_c = (uint32_t)((g_constrained->n_slots + G::SPW - 1) / G::SPW);
-      const size_t   lds    = (2 * (size_t)G::SPW * G::N3 + 2 * P * P * P + G::SPW) * sizeof(T);
-      if constexpr (G::SPW == 1 && G::N_INT > 0 && G::ROUNDS > 1)
-        if (use_persistent<T, P>())
-          {
-            const int resident = resident_workgroups(ctx);
-            uint32_t  np = pa.n_wg_plain, nc = n_wg_c;
-            if ((int)(np + nc) > resident)
-              { // every workgroup walks both kinds (kernels.hpp)
-                np = 0;
-                nc = (uint32_t)resident;
-              }
-            pa.n_wg_plain = np;
-            auto kern     = lattice_apply_persistent_pair_kernel<T, P, B, MODE>;
-            ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), lds);
-            hipLaunchKernelGGL(kern, np + nc, G::ABLOCK, lds, st, pa);
-            HIP_CHECK(hipGetLastError());
-            return;
-          }
-      auto           kern   = lattice_apply_pair_kernel<T, P, B, MODE>;
-      ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), lds);
-      hipLaunchKernelGGL(kern, pa.n_wg_plain + n_wg_c, G::ABLOCK, lds, st, pa);
-      HIP_CHECK(hipGetLastError());
-    }
-
-    template <int P, int MODE>
-    void
-    launch_group(hipStream_t st, ApplyArgs<T, P> &a, GroupDev<T> *g, GroupDev<T> *partner_cells, GroupDev<T> *partner_clusters,
-                 const T *src, const Epilogue<T> &epi, bool diag, size_t begin, size_t end, GroupDev<T> *partner_constrained = nullptr)
-    {
-      a.g      = (begin == 0 && end == g->n_slots) ? g->view() : g->view(begin, end);
-      if (partner_constrained)
-        {
-          if constexpr (P == 1)
-            {
-              if (g->B == 16)
-                return launch_pair<P, 16, MODE>(st, a, partner_constrained);
-              if (g->B == 8)
-                return launch_pair<P, 8, MODE>(st, a, partner_constrained);
-            }
-          throw std::runtime_error("brick pair launch: size not instantiated");
-        }
-      a.stamps = (stamps.p && g->B == prof_B && !g->constrained && MODE == stamp_mode && !diag && begin == 0) ? stamps.p : nullptr;
-      if (partner_clusters)
-        {
-          if constexpr (P == 1)
-            {
-              using G8 = Geo<1, 8>;
-              GroupDev<T>   *gc = partner_clusters;
-              P1SmallArgs<T> sa;
-              sa.a           = a;
-              sa.c           = cluster_args(*gc, src, epi, MODE == MODE_CHEB_FIRST);
-              sa.n_wg_bricks = (uint32_t)((g->n_slots + G8::SPW - 1) / G8::SPW);
-              const uint32_t n_wg_cl = (uint32_t)((gc->n_slots + CLUSTER_CELLS - 1) / CLUSTER_CELLS);
-              const size_t   lds     = std::max((2 * (size_t)G8::SPW * G8::N3 + 2 + G8::SPW) * sizeof(T),
-                                          2 * (size_t)std::max<uint32_t>(gc->max_uniq, 1) * sizeof(T));
-              hipLaunchKernelGGL((lattice_cluster_kernel<T, MODE>), sa.n_wg_bricks + n_wg_cl, 256, lds, st, sa);
-              HIP_CHECK(hipGetLastError());
-            }
-        }
-      else if (P == 1 && !diag && g->has_clusters())
-        launch_clusters(st, *g, src, epi, MODE == MODE_CHEB_FIRST);
-      else if (partner_cells)
-        {
-          if constexpr (P >= 2)
-            {
-              using G2 = Geo<P, 2>;
-              using G1 = Geo<P, 1>;
-              GroupDev<T>         *g1 = partner_cells;
-              SmallSlotsArgs<T, P> sa;
-              sa.a           = a;
-              sa.g_cells     = g1->view();
-              sa.n_wg_bricks = (uint32_t)((g->n_slots + G2::SPW - 1) / G2::SPW);
-              const uint32_t n_wg_cells = (uint32_t)((g1->n_slots + G1::SPW - 1) / G1::SPW);
-              const size_t   lds = (std::max(2 * (size_t)G2::SPW * G2::N3, 2 * (size_t)G1::SPW * G1::N3) + 2 * P * P * P + std::max(G2::SPW, G1::SPW)) * sizeof(T);
-              hipLaunchKernelGGL((lattice_apply_small_kernel<T, P, MODE>), sa.n_wg_bricks + n_wg_cells, 256, lds, st, sa);
-              HIP_CHECK(hipGetLastError());
-            }
-        }
-      else
-        dispatch_B<T, P, MODE>(ctx, st, g->B, g->constrained, a, diag);
-    }
-
-    template <int MODE>
-    void
-    launch_tail(hipStream_t st, uint32_t begin, uint32_t end, bool with_rest, const Epilogue<T> &epi_in, bool diag)
-    {
-      const uint32_t n_rest = with_rest ? tables->n_dofs - tables->n_interior - end : 0;
-      const uint32_t n_t    = end - begin + n_rest;
-      if (!n_t)
-        return;
-      Epilogue<T> epi = epi_in;
-      if (epi.dinv_code)
-        epi.dinv_code += begin;
-      if (diag)
-        hipLaunchKernelGGL((tail_kernel<T, MODE_INVDIAG>), grid_for(n_t), 256, 0, st, tail_acc.p + begin, tables->n_interior + begin, end - begin,
-                           n_rest, epi);
-      else
-        hipLaunchKernelGGL((tail_kernel<T, MODE>), grid_for(n_t), 256, 0, st, tail_acc.p + begin, tables->n_interior + begin, end - begin, n_rest,
-                           epi);
-      HIP_CHECK(hipGetLastError());
-    }
-
-    // One operator application.  Large levels run as a PIPELINE over two queues: the bricks of the dominant group go
-    // out in Morton chunks on the main queue; the small-slot kernels and, chunk by chunk, the epilogue of the tail DoFs
-    // that are complete after that chunk (LevelTables::tail_stage_end) run on the side queue underneath the next chunks.
-    // The brick kernel is latency-bound (2 workgroups per CU, sweeps between the memory phases), the tail epilogue is a
-    // pure stream without LDS: they share the CUs instead of running one after the other.
-    // Refinement-edge DoFs of a local-smoothing level (LevelTables::n_edge, numbered right after the tail):
-    //   EDGE_OUT   the level operator (Operator::vmult, ref:include/operator.h:152-183): zero input, identity rows
-    //   EDGE_ROWS  zero input, but their ROWS are computed: the residual that is restricted (deal.II edge_out /
-    //              vmult_interface_down)
-    //   EDGE_IN    ordinary unconstrained DoFs: the edge matrix (vmult_interface_up, ref:include/operator.h:203-226)
-    enum EdgeMode
-    {
-      EDGE_OUT  = 0,
-      EDGE_ROWS = 1,
-      EDGE_IN   = 2
-    };
-
-    template <int P, int MODE>
-    void
-    apply_P(const T *src, const Epilogue<T> &epi, bool diag, double words, int edge_mode)
-    {
-      ApplyArgs<T, P> a;
-      const uint32_t  first_edge = tables->n_interior + tables->n_tail;
-      a.gather_limit  = first_edge + (edge_mode == EDGE_IN ? tables->n_edge : 0);
-      a.scatter_limit = first_edge + (edge_mode != EDGE_OUT ? tables->n_edge : 0);
-      const uint32_t tail_end = tables->n_tail + (edge_mode != EDGE_OUT ? tables->n_edge : 0);
-      a.m          = mats<P>();
-      a.src        = src;
-      a.tail_acc   = tail_acc.p;
-      a.n_interior = tables->n_interior;
-      a.ablate     = ablate;
-      a.stamps     = nullptr;
-      a.epi        = epi;
-      // 2^3 bricks and single cells in one launch (lattice_apply_small_kernel) when both exist
-      GroupDev<T> *g2 = nullptr, *g1 = nullptr;
-      if (P >= 2 && !diag && merge_small)
-        for (auto &g : groups)
-          {
-            if (g->n_slots && g->B == 2)
-              g2 = g.get();
-            else if (g->n_slots && g->B == 1)
-              g1 = g.get();
-          }
-      const bool merged = g2 && g1;
-      // p = 1: the 8^3 bricks together with the cell clusters (lattice_cluster_kernel)
-      GroupDev<T> *g8 = nullptr, *gc = nullptr;
-      if (P == 1 && !diag && merge_small)
-        for (auto &g : groups)
-          {
-            if (g->n_slots && g->B == 8 && g->B != prof_B && !g->constrained)
-              g8 = g.get();
-            else if (g->n_slots && g->B == 1 && g->has_clusters())
-              gc = g.get();
-          }
-      const bool merged_p1 = g8 && gc;
-
-      // Sharded level: the slots that touch shared DoFs first (LevelTables puts them at the front of every group), then
-      // the halo exchange on the side queue UNDERNEATH the remaining slots (ref: MatrixFree::cell_loop overlaps its ghost
-      // exchange with the interior cell ranges, ref:include/operator.h:166-167).  Plain launches per group and range.
-      if (halo && !diag && halo_overlap)
-        {
-          auto halo_end = [&](const GroupDev<T> &g) -> size_t {
-            size_t nh = g.n_halo;
-            if (P == 1 && g.has_clusters()) // the cluster kernel works on whole 256-cell clusters
-              nh = std::min(g.n_slots, (nh + CLUSTER_CELLS - 1) / CLUSTER_CELLS * CLUSTER_CELLS);
-            return nh;
-          };
-          auto launch_range = [&](GroupDev<T> *g, size_t begin, size_t end) {
-            if (begin >= end)
-              return;
-            if (P == 1 && g->has_clusters())
-              launch_clusters(ctx->stream, *g, src, epi, MODE == MODE_CHEB_FIRST, (uint32_t)(begin / CLUSTER_CELLS),
-                              (uint32_t)((end + CLUSTER_CELLS - 1) / CLUSTER_CELLS));
-            else
-              {
-                a.g = g->view(begin, end);
-                dispatch_B<T, P, MODE>(ctx, ctx->stream, g->B, g->constrained, a, diag);
-              }
-          };
-          size_t n_interior_slots = 0;
-          for (auto &g : groups)
-            n_interior_slots += g->n_slots - halo_end(*g);
-          if (n_interior_slots > 0)
-            {
-              for (auto &g : groups)
-                launch_range(g.get(), 0, halo_end(*g));
-              ctx->order_after(ctx->side, ctx->stream); // the side queue waits for the halo slots only
-              // the exchange is enqueued BEFORE the interior slots: their persistent workgroups fill every CU's LDS until the
-              // launch ends, so RCCL's send/recv kernels must be resident first to run underneath them (the simulator's
-              // exchange blocks the host instead: no overlap there, same results)
-              exchange_add_raw(tail_acc.p, ctx->side);
-              for (auto &g : groups)
-                launch_range(g.get(), halo_end(*g), g->n_slots);
-              ctx->order_after(ctx->stream, ctx->side);
-              launch_tail<MODE>(ctx->stream, 0, tail_end, true, epi, diag);
-              return;
-            }
-        }
-      const int         pg        = tables->pipeline_group;
-      const bool        pipelined = !diag && pg >= 0 && !tables->chunk_slot_end.empty() && groups[pg]->n_slots > 0;
-      const hipStream_t main = ctx->stream, side = pipelined ? ctx->side : ctx->stream;
-      if (pipelined)
-        ctx->order_after(side, main); // the side queue starts where the main queue stands
-      auto prof_begin = [&](const GroupDev<T> &g) {
-        const bool prof = ctx->profile && !diag && MODE == MODE_CHEB && !g.constrained && g.B == (ctx->prof_brick ? ctx->prof_brick : prof_B);
-        if (prof)
-          {
-            if (ctx->prof_used == ctx->prof_events.size())
-              {
-                hipEvent_t e0, e1;
-                HIP_CHECK(hipEventCreate(&e0));
-                HIP_CHECK(hipEventCreate(&e1));
-                ctx->prof_events.push_back({e0, e1});
-              }
-            HIP_CHECK(hipEventRecord(ctx->prof_events[ctx->prof_used].first, main));
-          }
-        return prof;
-      };
-      auto prof_end = [&](const GroupDev<T> &g, size_t n_slots) {
-        HIP_CHECK(hipEventRecord(ctx->prof_events[ctx->prof_used].second, main));
-        ++ctx->prof_used;
-        // algorithmic bytes of THIS kernel: `words` per slot-interior DoF (the fused epilogue is complete for them); for
-        // the (N-1)^3 - (N-2)^3 shell DoFs a brick is responsible for, one gathered word and one partial sum (the other
-        // words of their epilogue are tail_kernel's)
-        // (D^-1 of slot-interior DoFs is evaluated in closed form, not read, by the p = 1 kernels and by the persistent
-        // 17-point lattice kernels: one word less per interior DoF)
-        // prof_bytes keeps SURVEY 8(d)'s per-unit figure (the algorithm's words); prof_bytes_moved is the kernel's own count
-        const bool   closed_dinv = P == 1 || (g.N * g.N > 256 && use_persistent<T, P>());
-        const double w_interior  = words - (closed_dinv ? 1.0 : 0.0);
-        const double n1 = (double)(g.N - 1), n2 = (double)(g.N - 2);
-        ctx->prof_bytes += sizeof(T) * (double)n_slots * (words * n2 * n2 * n2 + 2.0 * (n1 * n1 * n1 - n2 * n2 * n2));
-        ctx->prof_bytes_moved += sizeof(T) * (double)n_slots * (w_interior * n2 * n2 * n2 + 2.0 * (n1 * n1 * n1 - n2 * n2 * n2));
-      };
-      // plain + constrained bricks of one size share a launch (p = 1: the only degree with constrained bricks above B = 2)
-      auto constrained_partner = [&](GroupDev<T> *g) -> GroupDev<T> * {
-        if (P != 1 || diag || !merge_small || pipelined || g->constrained || g->B <= 2 || (merged_p1 && g == g8))
-          return nullptr;
-        for (auto &q : groups)
-          if (q->constrained && q->B == g->B && q->n_slots)
-            return q.get();
-        return nullptr;
-      };
-      // every group but the pipelined one
-      for (size_t gi = 0; gi < groups.size(); ++gi)
-        {
-          GroupDev<T> *g = groups[gi].get();
-          if (!g->n_slots || (pipelined && (int)gi == pg))
-            continue;
-          if ((merged && g == g1) || (merged_p1 && g == gc))
-            continue; // done together with the 2^3 (8^3) bricks
-          if (g->constrained && !diag && merge_small && !pipelined && P == 1)
-            {
-              bool has_plain = false;
-              for (auto &q : groups)
-                has_plain |= !q->constrained && q->B == g->B && q->n_slots && !(merged_p1 && q.get() == g8);
-              if (has_plain)
-                continue; // launched together with the plain bricks of its size
-            }
-          const bool prof = !pipelined && prof_begin(*g);
-          launch_group<P, MODE>(side, a, g, (merged && g == g2) ? g1 : nullptr, (merged_p1 && g == g8) ? gc : nullptr, src, epi, diag, 0,
-                                g->n_slots, constrained_partner(g));
-          if (prof)
-            prof_end(*g, g->n_slots);
-        }
-      uint32_t tail_done = 0;
-      if (pipelined)
-        {
-          GroupDev<T> *g     = groups[pg].get();
-          uint32_t     begin = 0;
-          for (size_t c = 0; c < tables->chunk_slot_end.size(); ++c)
-            {
-              const uint32_t end  = tables->chunk_slot_end[c];
-              const bool     prof = prof_begin(*g);
-              launch_group<P, MODE>(main, a, g, nullptr, nullptr, src, epi, diag, begin, end);
-              if (prof)
-                prof_end(*g, end - begin);
-              begin = end;
-              if (tables->tail_stage_end[c] > tail_done)
-                {
-                  ctx->order_after(side, main);
-                  launch_tail<MODE>(side, tail_done, tables->tail_stage_end[c], false, epi, diag);
-                  tail_done = tables->tail_stage_end[c];
-                }
-            }
-          ctx->order_after(main, side); // join
-        }
-      if (halo)
-        exchange_add_raw(tail_acc.p); // complete the shared tail sums across ranks before the epilogue
-      launch_tail<MODE>(main, tail_done, tail_end, true, epi, diag);
-    }
-
-    template <int MODE>
-    void
-    apply(const T *src, const Epilogue<T> &epi, bool diag = false, double words = 0, int edge_mode = EDGE_OUT)
-    {
-      switch (p)
-        {
-          case 1:
-            apply_P<1, MODE>(src, epi, diag, words, edge_mode);
-            break;
-          case 2:
-            apply_P<2, MODE>(src, epi, diag, words, edge_mode);
-            break;
-          case 3:
-            apply_P<3, MODE>(src, epi, diag, words, edge_mode);
-            break;
-          case 4:
-            apply_P<4, MODE>(src, epi, diag, words, edge_mode);
-            break;
-          default:
-            throw std::runtime_error("degree not instantiated");
-        }
-    }
-
-    // raw-pointer entry points used by smoother / multigrid
-    void
-    vmult_raw(T *dst, const T *src)
-    {
-      Epilogue<T> e{dst, src, nullptr, nullptr, nullptr, T(0), T(0), T(0)};
-      apply<MODE_VMULT>(src, e);
-    }
-    void
-    residual_raw(T *t, const T *b, const T *x) // t = b - A x
-    {
-      Epilogue<T> e{t, x, nullptr, b, nullptr, T(0), T(0), T(0)};
-      if (tables->n_edge == 0)
-        {
-          apply<MODE_RESIDUAL>(x, e);
-          return;
-        }
-      // local-smoothing level: the rows of the refinement-edge DoFs belong to the residual that is restricted,
-      // t_E = b_E - x_E - A_{E,I} x_I (identity row + coupling to the interior of the refined region)
-      apply<MODE_RESIDUAL>(x, e, false, 0, EDGE_ROWS);
-      const size_t first_edge = (size_t)tables->n_interior + tables->n_tail;
-      hipLaunchKernelGGL(vec_sadd_kernel<T>, grid_for(tables->n_edge), 256, 0, ctx->stream, t + first_edge, T(1), T(-1), x + first_edge,
-                         (size_t)tables->n_edge);
-    }
-    // dst = A^{edge DoFs unconstrained} (src restricted to the refinement-edge DoFs); tmp: scratch of n_dofs entries
-    // (Operator::vmult_interface_up, ref:include/operator.h:203-226)
-    void
-    interface_up_raw(T *dst, const T *src, T *tmp)
-    {
-      const size_t n = n_dofs(), first_edge = (size_t)tables->n_interior + tables->n_tail;
-      HIP_CHECK(hipMemsetAsync(tmp, 0, n * sizeof(T), ctx->stream));
-      if (tables->n_edge)
-        HIP_CHECK(hipMemcpyAsync(tmp + first_edge, src + first_edge, (size_t)tables->n_edge * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
-      Epilogue<T> e{dst, tmp, nullptr, nullptr, nullptr, T(0), T(0), T(0)};
-      apply<MODE_VMULT>(tmp, e, false, 0, EDGE_IN);
-    }
-    void
-    vmult_interface_up(mgamd_vec &dst, const mgamd_vec &src) override
-    {
-      if (dst.n != n_dofs() || src.n != n_dofs() || dst.data == src.data)
-        throw std::invalid_argument("vmult_interface_up: bad vectors");
-      DBuf<T> tmp;
-      tmp.alloc(n_dofs());
-      interface_up_raw(dst.as<T>(), src.as<T>(), tmp.p);
-      ctx->sync();
-    }
-    // One-byte codes for D^-1 of the DoFs tail_kernel handles (tail, refinement-edge, Dirichlet, hanging): on a level only a
-    // few hundred distinct values occur there (node type x cell size x summation order), so the 255 most frequent ones go
-    // into a table and the rest keeps reading the vector.  Values are matched by bit pattern: results do not change.
-    void
-    build_dinv_codes(const T *dinv)
-    {
-      dinv_coded = nullptr;
-      if (getenv("MGAMD_NO_DINV_CODES"))
-        return;
-      const size_t n0 = tables->n_interior, n = (size_t)n_dofs() - n0;
-      if (n < 4096) // small levels are latency-bound: nothing to gain
-        return;
-      std::vector<T> h(n);
-      ctx->sync();
-      HIP_CHECK(hipMemcpy(h.data(), dinv + n0, n * sizeof(T), hipMemcpyDeviceToHost));
-      using Bits = typename std::conditional<sizeof(T) == 8, uint64_t, uint32_t>::type;
-      std::unordered_map<Bits, uint32_t> count;
-      count.reserve(1024);
-      auto bits = [](T v) {
-        Bits b;
-        std::memcpy(&b, &v, sizeof(T));
-        return b;
-      };
-      for (size_t i = 0; i < n && count.size() < (1u << 20); ++i)
-        ++count[bits(h[i])];
-      std::vector<std::pair<uint32_t, Bits>> top;
-      top.reserve(count.size());
-      for (auto &kv : count)
-        top.push_back({kv.second, kv.first});
-      std::sort(top.begin(), top.end(), [](const auto &a, const auto &b) { return a.first > b.first || (a.first == b.first && a.second < b.second); });
-      if (top.size() > 255)
-        top.resize(255);
-      std::vector<T>                    table(256, T(1));
-      std::unordered_map<Bits, uint8_t> code_of;
-      for (size_t k = 0; k < top.size(); ++k)
-        {
-          std::memcpy(&table[k], &top[k].second, sizeof(T));
-          code_of[top[k].second] = (uint8_t)k;
-        }
-      std::vector<uint8_t> codes(n);
-      for (size_t i = 0; i < n; ++i)
-        {
-          auto it  = code_of.find(bits(h[i]));
-          codes[i] = it == code_of.end() ? (uint8_t)255 : it->second;
-        }
-      dinv_code.upload(codes);
-      dinv_table.upload(table);
-      dinv_coded = dinv;
-    }
-
-    void
-    cheb_raw(T *out, const T *x, const T *xold, const T *b, const T *dinv, double f1, double f2, int from_b = 0, double c0 = 0.0)
-    {
-      // from_b = 1: x is c0 dinv b and xold = 0 (x is not read); from_b = 2: xold is c0 dinv b (xold is not read)
-      Epilogue<T> e{out, x, from_b ? nullptr : xold, b, dinv, T(f1), T(f2), T(c0)};
-      if (dinv == dinv_coded && dinv_code.p)
-        {
-          e.dinv_code  = dinv_code.p;
-          e.dinv_table = dinv_table.p;
-        }
-      if (from_b == 1)
-        apply<MODE_CHEB_FIRST>(x, e, false, 3.0);
-      else if (from_b == 2)
-        apply<MODE_CHEB_SECOND>(x, e, false, 4.0);
-      else
-        apply<MODE_CHEB>(x, e, false, xold ? 5.0 : 4.0);
-    }
-
-    void
-    vmult(mgamd_vec &dst, const mgamd_vec &src) override
-    {
-      if (dst.n != n_dofs() || src.n != n_dofs())
-        throw std::invalid_argument("vmult: vector size mismatch");
-      if (dst.data == src.data)
-        throw std::invalid_argument("vmult: dst and src must differ");
-      vmult_raw(dst.as<T>(), src.as<T>());
-    }
-
-    size_t
-    read_debug_stamps(unsigned long long *out, size_t max_count) override
-    {
-      ctx->sync();
-      const size_t n = std::min(max_count, stamps.n);
-      if (n)
-        HIP_CHECK(hipMemcpy(out, stamps.p, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-      return n;
-    }
-
-    void
-    compute_inverse_diagonal(mgamd_vec &d) override
-    {
-      if (d.n != n_dofs())
-        throw std::invalid_argument("compute_inverse_diagonal: vector size mismatch");
-      Epilogue<T> e{d.as<T>(), nullptr, nullptr, nullptr, nullptr, T(0), T(0)};
-      apply<MODE_VMULT>(nullptr, e, true);
-    }
-  };
 
   LevelOperatorBase *
   make_level_operator(Ctx *ctx, const mgamd_dofs *dofs, int type, std::shared_ptr<Comm> comm)

@@ -97,10 +97,6 @@ typedef struct
 int mgamd_dofs_create(const mgamd_tria *t, int degree, int max_brick, mgamd_dofs **out);
 int mgamd_dofs_destroy(mgamd_dofs *d);
 int mgamd_dofs_info(const mgamd_dofs *d, mgamd_dofs_info_t *info);
-/* pipelined operator pass: the slots of group `*group` (-1: level not pipelined) are launched in
- * *n_chunks Morton chunks ending at chunk_slot_end[c]; the owned tail DoFs [tail_stage_end[c-1], tail_stage_end[c]) (tail
- * indices = global index - n_interior) are complete once chunk c has run.  Arrays of up to 16 entries, may be NULL. */
-int mgamd_dofs_pipeline(const mgamd_dofs *d, int *group, uint32_t *n_chunks, uint32_t *chunk_slot_end, uint32_t *tail_stage_end);
 /* slot group and slot index of every cell (0xFE: cell of another rank) */
 int mgamd_dofs_get_cell_slots(const mgamd_dofs *d, uint8_t *group, uint32_t *slot);
 /* geometric identity of each DoF: keys[5*i..] = {px,py,pz,dirmask,level} (tests / oracle matching) */

@@ -298,18 +298,12 @@ def test_gaussian_simulation_type_solve(mgamd, oracle, ctx, hierarchies, geo, L,
     assert rel_err(x.to_host(), Lf.distribute(xref, oracle.gaussian_solution)) < 10 * TOL_SOL
 
 
-@pytest.mark.parametrize("geo,L,p,chunks", [("hypercube", 3, 4, 3), ("hypercube", 5, 1, 4), ("hypercube", 4, 2, 2)])
-def test_pipelined_operator_pass(mgamd, oracle, ctx, geo, L, p, chunks, monkeypatch):
-    """Large levels run the operator as a two-queue pipeline (brick chunks on the main queue, small slots and the staged
-    tail epilogue on the side queue).  Forced here on small meshes: every mode of the fused kernels
-    (vmult, residual inside the V-cycle, the three Chebyshev variants) against the numpy oracle, and identical to the
-    un-pipelined pass."""
-    monkeypatch.setenv("MGAMD_PIPELINE", "1")
-    monkeypatch.setenv("MGAMD_PIPELINE_MIN_SLOTS", "1")
-    monkeypatch.setenv("MGAMD_PIPELINE_CHUNKS", str(chunks))
+@pytest.mark.parametrize("geo,L,p", [("hypercube", 3, 4), ("hypercube", 5, 1), ("hypercube", 4, 2)])
+def test_brick_levels_every_mode(mgamd, oracle, ctx, geo, L, p):
+    """Levels forced onto the largest bricks (max_brick=0: several 17-point lattices sharing faces, edges and vertices):
+    every mode of the fused kernels (vmult, residual and transfers inside the V-cycle, the three Chebyshev variants) against
+    the numpy oracle; repeated applications (the tail accumulator must be clean after every pass)."""
     h = mgamd.Hierarchy(ctx, geo, L, p, "HMG-global", coarse_solver="amg", max_brick=0)
-    grp, chunk_end, stage_end = h.dofs[-1].pipeline()
-    assert grp >= 0 and len(chunk_end) == chunks and stage_end[0] > 0
     levels, P = oracle.build_hierarchy(geo, L, p, "HMG-global", numbering_keys=[d.keys() for d in h.dofs])
     lv, op = levels[-1], h.operators[-1]
     rng = np.random.default_rng(31)
@@ -337,28 +331,6 @@ def test_pipelined_operator_pass(mgamd, oracle, ctx, geo, L, p, chunks, monkeypa
     h.fine_operator.rhs(vb2)
     it, res = mgamd.solve_cg(h.fine_operator, h.mg, vx2, vb2, 1e-4)
     assert it == itref and rel_err(vx2.to_host(), xref) < TOL_SOL
-
-
-def test_pipelined_pass_at_scale_matches_unpipelined(mgamd, ctx, monkeypatch):
-    """octant L=6 p=4 (2.3 M DoFs, 343 bricks of 4^3 cells + constrained families + single cells) and octant L=8 p=1: the
-    pipelined V-cycle equals the un-pipelined one through the DoF keys (different tail numbering, same operator)."""
-    for geo, L, p in (("quadrant", 6, 4), ("quadrant", 8, 1)):
-        monkeypatch.setenv("MGAMD_CHEB_KEY_INIT", "1")
-        monkeypatch.setenv("MGAMD_PIPELINE", "1")
-        monkeypatch.setenv("MGAMD_PIPELINE_MIN_SLOTS", "1")
-        ha = mgamd.Hierarchy(ctx, geo, L, p, "HMG-global", coarse_solver="amg")
-        assert ha.dofs[-1].pipeline()[0] >= 0
-        monkeypatch.setenv("MGAMD_PIPELINE_MIN_SLOTS", "1000000000")
-        hb = mgamd.Hierarchy(ctx, geo, L, p, "HMG-global", coarse_solver="amg")
-        assert hb.dofs[-1].pipeline()[0] < 0
-        ka, kb = ha.dofs[-1].keys(), hb.dofs[-1].keys()
-        pos = {tuple(k): i for i, k in enumerate(kb.tolist())}
-        perm = np.array([pos[tuple(k)] for k in ka.tolist()])
-        rb = np.random.default_rng(5).standard_normal(len(kb))
-        za, zb = mgamd.Vector(ctx, len(ka)), mgamd.Vector(ctx, len(kb))
-        ha.mg.vmult(za, mgamd.Vector(ctx, len(ka)).from_host(rb[perm]))
-        hb.mg.vmult(zb, mgamd.Vector(ctx, len(kb)).from_host(rb))
-        assert rel_err(za.to_host(), zb.to_host()[perm]) < 1e-11
 
 
 def test_event_stage_timing(mgamd, ctx):

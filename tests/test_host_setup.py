@@ -208,35 +208,6 @@ def test_gaussian_right_hand_side_and_distribute(mgamd, oracle, geo, L, p):
     assert np.abs(x0 - lv.distribute(x, lambda a, b, c: 0 * a)).max() <= 1e-13 * np.abs(x).max()
 
 
-@pytest.mark.parametrize("geo,L,p,chunks", [("quadrant", 4, 4, 3), ("hypercube", 5, 1, 4), ("annulus", 6, 2, 2), ("hypercube", 3, 4, 4)])
-def test_pipeline_stages_of_the_tail(mgamd, oracle, geo, L, p, chunks, monkeypatch):
-    """pipelined operator pass: the owned tail is ordered by completion stage -- a DoF of stage c is touched by slots of
-    the pipelined group in chunks <= c only (and by no other group); the renumbering changes no operator entry"""
-    monkeypatch.setenv("MGAMD_PIPELINE", "1")
-    monkeypatch.setenv("MGAMD_PIPELINE_MIN_SLOTS", "1")
-    monkeypatch.setenv("MGAMD_PIPELINE_CHUNKS", str(chunks))
-    t = mgamd.Triangulation(geo, L)
-    d = mgamd.DoFs(t, p, 0)
-    grp, chunk_end, stage_end = d.pipeline()
-    assert grp >= 0 and len(chunk_end) == chunks and chunk_end[-1] == d.groups()[grp][1]
-    assert all(a <= b for a, b in zip(stage_end, stage_end[1:])) and stage_end[-1] <= d.info.n_tail_owned
-    cg, cs = d.cell_slots()
-    cd = d.cell_dofs()
-    ni, nt = d.info.n_interior, d.info.n_tail
-    need = np.zeros(nt, np.int64)  # the stage each tail DoF needs: max over the touching cells
-    for ci in range(t.n_cells):
-        st = int(np.searchsorted(chunk_end, cs[ci], side="right")) if cg[ci] == grp else chunks
-        idx = cd[ci]
-        idx = idx[(idx != mgamd.INVALID_DOF) & (idx >= ni) & (idx < ni + nt)] - ni
-        need[idx] = np.maximum(need[idx], st)
-    have = np.searchsorted(stage_end, np.arange(nt), side="right")  # the stage the numbering puts it in
-    assert np.array_equal(have, need)
-    assert stage_end[0] > 0  # something does overlap
-    # same operator as without the staging (numbering-independent check through the oracle)
-    lv = oracle_level(oracle, d, geo, L, p)
-    assert d.n_dofs == lv.n and np.abs(d.rhs_constant() - lv.rhs_constant).max() < 1e-15
-
-
 @pytest.mark.parametrize("geo,L,p", [("quadrant", 3, 1), ("quadrant", 4, 2), ("annulus", 5, 1), ("quadrant", 3, 4)])
 def test_local_smoothing_level_tables(mgamd, geo, L, p):
     """HMG-local host tables against the textbook oracle: level meshes (all cells of a refinement level), DoF counts,

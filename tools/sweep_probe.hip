@@ -9,6 +9,175 @@
 #include <cstdio>
 #include <vector>
 
+// The 512-thread sweeps measured here lived in kernels.hpp while a whole-kernel variant used them (round 2: not faster, see
+// DESIGN.md); they are kept with their only user.
+namespace mgamd
+{
+  // ---- WIDE sweeps: 512 threads on one 17-point lattice (4 waves per SIMD with two workgroups per CU instead of 2).
+  // A sweep is 512 half-line tasks (lines 0..255, nodes 8 s .. 8 s + 7 (+ 16), s = tid & 1: the two halves of a line in
+  // adjacent lanes) followed by 132 quarter-line tasks for the 33 left-over lines (as in lattice_sweeps).  A task of SEGN
+  // nodes reads, UP FRONT, the P nodes of the cell to its left (whose last row acts on its first node) and the node to its
+  // right (owned, and overwritten early, by the next task of the line); all tasks of a line sit in one wavefront and run in
+  // lock step, so every lane has these before any lane stores (seg_fence).  Its own nodes are streamed cell by cell.
+  // KIND as in line_stream.  A, Bb point at the task's first node.
+  template <typename T, int P, int KIND, int SEGN>
+  __device__ __forceinline__ void
+  seg_task(const Mats<P> &m, T *__restrict__ A, T *__restrict__ Bb, const int stride, const bool has_left, const bool is_last,
+           const T scale)
+  {
+    static_assert(SEGN % P == 0, "segment = whole cells");
+    constexpr int n = P + 1, CPS = SEGN / P;
+    T             la[n], lb[n];
+#pragma unroll
+    for (int j = 0; j < P; ++j)
+      {
+        la[j] = has_left ? A[(j - P) * stride] : T(0);
+        lb[j] = (KIND != 0 && has_left) ? Bb[(j - P) * stride] : T(0);
+      }
+    la[P]      = A[0];
+    lb[P]      = KIND != 0 ? Bb[0] : T(0);
+    const T ra = A[SEGN * stride], rb = KIND != 0 ? Bb[SEGN * stride] : T(0);
+    seg_fence();
+    T c1 = T(0), c2 = T(0);
+#pragma unroll
+    for (int j = 0; j <= P; ++j)
+      {
+        const T Mj = T(m.M[P * (P + 1) + j]), Kj = T(m.K[P * (P + 1) + j]);
+        if (KIND != 2)
+          c1 += Mj * la[j];
+        c2 += Kj * la[j];
+        if (KIND != 0)
+          c2 += Mj * lb[j];
+      }
+    if (!has_left)
+      c1 = c2 = T(0);
+    T a[n], b[n];
+    a[0] = la[P];
+    b[0] = lb[P];
+#pragma unroll
+    for (int c = 0; c < CPS; ++c)
+      {
+#pragma unroll
+        for (int j = 1; j < n; ++j)
+          {
+            const bool right = c == CPS - 1 && j == P;
+            a[j]             = right ? ra : A[(c * P + j) * stride];
+            if (KIND != 0)
+              b[j] = right ? rb : Bb[(c * P + j) * stride];
+          }
+        T o1[n], o2[n];
+#pragma unroll
+        for (int i = 0; i < n; ++i)
+          o1[i] = o2[i] = T(0);
+        if constexpr (P < 4)
+          {
+#pragma unroll
+            for (int i = 0; i < n; ++i)
+#pragma unroll
+              for (int j = 0; j < n; ++j)
+                {
+                  if (KIND != 2)
+                    o1[i] += T(m.M[i * n + j]) * a[j];
+                  o2[i] += T(m.K[i * n + j]) * a[j];
+                  if (KIND != 0)
+                    o2[i] += T(m.M[i * n + j]) * b[j];
+                }
+          }
+        else
+          {
+            EvenOdd<T, P> xa, xb, y;
+            xa.split(a);
+            if (KIND != 0)
+              xb.split(b);
+            if (KIND != 2)
+              {
+                y.template apply<false>(m.Me, m.Mo, xa);
+                y.add_to(o1);
+              }
+            y.template apply<false>(m.Ke, m.Ko, xa);
+            if (KIND != 0)
+              y.template apply<true>(m.Me, m.Mo, xb);
+            y.add_to(o2);
+          }
+        o1[0] += c1;
+        o2[0] += c2;
+#pragma unroll
+        for (int j = 0; j < P; ++j)
+          {
+            if (KIND != 2)
+              {
+                A[(c * P + j) * stride]  = o1[j];
+                Bb[(c * P + j) * stride] = o2[j];
+              }
+            else
+              A[(c * P + j) * stride] = scale * o2[j];
+          }
+        c1   = o1[P];
+        c2   = o2[P];
+        a[0] = a[P];
+        b[0] = b[P];
+      }
+    if (is_last)
+      {
+        if (KIND != 2)
+          {
+            A[SEGN * stride]  = c1;
+            Bb[SEGN * stride] = c2;
+          }
+        else
+          A[SEGN * stride] = scale * c2;
+      }
+  }
+
+  // the three sweeps of ONE 17-point lattice with 512 threads; ends with a barrier
+  template <typename T, int P, typename Hook = NoHook>
+  __device__ __forceinline__ void
+  lattice_sweeps_wide(T *__restrict__ bufA, T *__restrict__ bufB, const Mats<P> &m, const int tid, const T h, const Hook &before_x = Hook())
+  {
+    static_assert(16 % P == 0 && 8 % P == 0 && 4 % P == 0, "17-point lattices: P in {1, 2, 4}");
+    constexpr int N = 17;
+    // half-line task: line tid / 2, half tid % 2;  quarter-line task (tid < 132): line 256 + tid / 4, quarter tid % 4
+    const int  hl = tid >> 1, hs = tid & 1, hu = hl % N, hv = hl / N;
+    const int  ql = 256 + (tid >> 2), qs = tid & 3, qu = ql % N, qv = ql / N;
+    const bool qt = tid < 4 * (N * N - 256);
+    // z sweep: line (x = u, y = v), stride N^2
+    {
+      const int base = hv * N + hu + 8 * hs * N * N;
+      seg_task<T, P, 0, 8>(m, bufA + base, bufB + base, N * N, hs > 0, hs == 1, T(1));
+      if (qt)
+        {
+          const int b2 = qv * N + qu + 4 * qs * N * N;
+          seg_task<T, P, 0, 4>(m, bufA + b2, bufB + b2, N * N, qs > 0, qs == 3, T(1));
+        }
+    }
+    __syncthreads();
+    // y sweep: line (x = u, z = v), stride N
+    {
+      const int base = hv * N * N + hu + 8 * hs * N;
+      seg_task<T, P, 1, 8>(m, bufA + base, bufB + base, N, hs > 0, hs == 1, T(1));
+      if (qt)
+        {
+          const int b2 = qv * N * N + qu + 4 * qs * N;
+          seg_task<T, P, 1, 4>(m, bufA + b2, bufB + b2, N, qs > 0, qs == 3, T(1));
+        }
+    }
+    __syncthreads();
+    before_x();
+    // x sweep: line (y = u, z = v), stride 1
+    {
+      const int base = (hv * N + hu) * N + 8 * hs;
+      seg_task<T, P, 2, 8>(m, bufA + base, bufB + base, 1, hs > 0, hs == 1, h);
+      if (qt)
+        {
+          const int b2 = (qv * N + qu) * N + 4 * qs;
+          seg_task<T, P, 2, 4>(m, bufA + b2, bufB + b2, 1, qs > 0, qs == 3, h);
+        }
+    }
+    __syncthreads();
+  }
+
+} // namespace mgamd
+
 using namespace mgamd;
 
 constexpr int P = 4, B = 4, N = 17, N3 = N * N * N;
