@@ -483,6 +483,12 @@ class MGTwoLevelTransfer:
     def restrict_and_add(self, dst_coarse: Vector, src_fine: Vector):
         _chk(_lib.mgamd_transfer2_restrict_and_add(self._h, dst_coarse._h, src_fine._h))
 
+    def n_fused_bricks(self):
+        """fine bricks whose share of this transfer runs inside the operator passes of the V-cycle (0: none)"""
+        n = C.c_uint64()
+        _chk(_lib.mgamd_transfer2_n_fused_bricks(self._h, C.byref(n)))
+        return n.value
+
     def __del__(self):
         if getattr(self, "_h", None) and _lib is not None:
             _lib.mgamd_transfer2_destroy(self._h)

@@ -11,11 +11,20 @@ namespace mgamd
 {
 #define MGAMD_INST(MODE)                                                                                                                  \
   template void LevelOperator<MGAMD_INST_T>::apply_P<MGAMD_INST_P, MODE>(const MGAMD_INST_T *, const Epilogue<MGAMD_INST_T> &, bool, double, \
-                                                                         int);
+                                                                         int, const FusedTransferHost<MGAMD_INST_T> *);
   MGAMD_INST(MODE_VMULT)
   MGAMD_INST(MODE_RESIDUAL)
   MGAMD_INST(MODE_CHEB)
   MGAMD_INST(MODE_CHEB_FIRST)
   MGAMD_INST(MODE_CHEB_SECOND)
+  // the passes with fused level transfers: degrees with a persistent 17-point lattice kernel (not float at p = 4, see
+  // use_persistent in level_operator.hpp)
+#define MGAMD_IS_float 1
+#define MGAMD_CAT_(a, b) a##b
+#define MGAMD_CAT(a, b) MGAMD_CAT_(a, b)
+#if (MGAMD_INST_P == 1 || MGAMD_INST_P == 2 || MGAMD_INST_P == 4) && !(MGAMD_INST_P == 4 && MGAMD_CAT(MGAMD_IS_, MGAMD_INST_T) + 0 == 1)
+  MGAMD_INST(MODE_RESIDUAL_RESTRICT)
+  MGAMD_INST(MODE_CHEB_PROLONGATE)
+#endif
 #undef MGAMD_INST
 } // namespace mgamd

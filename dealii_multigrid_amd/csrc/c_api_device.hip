@@ -494,6 +494,15 @@ mgamd_transfer2_restrict_and_add(mgamd_transfer2 *t, mgamd_vec *dst_coarse, cons
 }
 
 int
+mgamd_transfer2_n_fused_bricks(const mgamd_transfer2 *t, uint64_t *n)
+{
+  MGAMD_TRY
+  REQUIRE(t && n);
+  *n = t->t->n_fused_bricks_total();
+  MGAMD_CATCH
+}
+
+int
 mgamd_mg_create(mgamd_ctx *ctx, unsigned n_levels, mgamd_level_op *const *levels, mgamd_transfer2 *const *transfers,
                 mgamd_cheb *const *smoothers, const char *coarse_solver, mgamd_mg **out)
 {

@@ -108,8 +108,19 @@ namespace mgamd
     MODE_INVDIAG  = 3, // out = |d| > 1e-10 ? 1/d : 1                       (d delivered as 'A x')
     // zero-start Chebyshev without materialising x_1 = c0 dinv b:
     MODE_CHEB_FIRST  = 4, // MODE_CHEB with x := c0 dinv b computed on the fly (no x, no xold is read)
-    MODE_CHEB_SECOND = 5  // MODE_CHEB with xold := c0 dinv b computed on the fly
+    MODE_CHEB_SECOND = 5, // MODE_CHEB with xold := c0 dinv b computed on the fly
+    // level transfers FUSED into the operator pass that holds the same 17-point lattice in LDS (persistent brick kernel only;
+    // every other kernel of such a pass runs the base mode):
+    MODE_RESIDUAL_RESTRICT = 6, // MODE_RESIDUAL; bricks flagged as fused restrict their part of b - A x into the coarse defect
+                                // (interior rows complete, shell rows as partial sums) instead of storing it
+    MODE_CHEB_PROLONGATE = 7    // MODE_CHEB (x_old = 0: first pass of a smoothing step) on x + P x_c: fused bricks add the
+                                // coarse correction on their lattice while gathering x and store x + P x_c once
   };
+  constexpr int
+  base_mode(int mode)
+  {
+    return mode == MODE_RESIDUAL_RESTRICT ? MODE_RESIDUAL : (mode == MODE_CHEB_PROLONGATE ? MODE_CHEB : mode);
+  }
 
   template <typename T>
   struct Epilogue
@@ -125,6 +136,12 @@ namespace mgamd
     // of this level (255: read dinv[]); entry i belongs to DoF n_interior + i.  Bit-identical values, 7 bytes less per DoF.
     const uint8_t *dinv_code  = nullptr;
     const T       *dinv_table = nullptr;
+    // tail_kernel<MODE_CHEB_PROLONGATE> only: tail DoF n_interior + i with xs_flag[i] != 0 is owned by a fused brick, which has
+    // left x_i + (P x_c)_i in xs (indexed like x); the kernel uses it as x and stores it to x_inout (= x), so that the next pass
+    // finds x + P x_c everywhere
+    const uint8_t *xs_flag = nullptr;
+    const T       *xs      = nullptr;
+    T             *x_inout = nullptr;
   };
   constexpr bool
   is_cheb(int mode)
@@ -849,6 +866,56 @@ namespace mgamd
       }
   }
 
+  // ---- 1D embedding of the h-transfer along one lattice line (brick transfers and the transfers fused into the operator)
+  // fine line (P*BC*2+1) from coarse line (P*BC+1), cell by cell
+  template <typename T, int P, int BC>
+  __device__ __forceinline__ void
+  line_embed(const double *__restrict__ E, const T (&in)[P * BC + 1], T (&out)[2 * P * BC + 1])
+  {
+#pragma unroll
+    for (int c = 0; c < BC; ++c)
+#pragma unroll
+      for (int a = (c == 0 ? 0 : 1); a <= 2 * P; ++a)
+        {
+          T s = T(0);
+#pragma unroll
+          for (int b = 0; b <= P; ++b)
+            s += T(E[a * (P + 1) + b]) * in[c * P + b];
+          out[c * 2 * P + a] = s;
+        }
+  }
+  // transpose: coarse line += E^T fine line; fine nodes shared by two coarse cells are counted once
+  template <typename T, int P, int BC>
+  __device__ __forceinline__ void
+  line_embed_T(const double *__restrict__ E, const T (&in)[2 * P * BC + 1], T (&out)[P * BC + 1])
+  {
+#pragma unroll
+    for (int i = 0; i < P * BC + 1; ++i)
+      out[i] = T(0);
+#pragma unroll
+    for (int c = 0; c < BC; ++c)
+#pragma unroll
+      for (int a = (c == 0 ? 0 : 1); a <= 2 * P; ++a)
+#pragma unroll
+        for (int b = 0; b <= P; ++b)
+          out[c * P + b] += T(E[a * (P + 1) + b]) * in[c * 2 * P + a];
+  }
+
+  // Tables of the transfers fused into the operator (Transfer2 in runtime.hip builds them, indexed by SLOT of the fused group):
+  //   flags[slot * 256 + tid]  bit 15: the slot is fused; bits 2 it, 2 it + 1: BrickTransferGroup::SHELL_OWN / SHELL_OTHER of
+  //                            shell entry tid + 256 it of that slot
+  //   coarse_idx[slot * NC^3 + c]  coarse DoF of coarse lattice node c (x fastest), DEV_INVALID = Dirichlet or slot not fused
+  template <typename T, int P>
+  struct FusedTransferDev
+  {
+    const uint16_t *flags      = nullptr;
+    const uint32_t *coarse_idx = nullptr;
+    double          E[(2 * P + 1) * (P + 1)];
+    T              *coarse  = nullptr; // RESTRICT: the coarse defect (+=);  PROLONGATE: the coarse solution (read only)
+    T              *x_inout = nullptr; // PROLONGATE: == src; x + P x_c of the fused bricks' interior DoFs is stored in place
+    T              *scratch = nullptr; // PROLONGATE: x + P x_c of the shell DoFs a fused brick owns (indexed like x)
+  };
+
   template <typename T, int P>
   struct ApplyArgs
   {
@@ -865,6 +932,7 @@ namespace mgamd
     // refinement-edge DoFs right after the tail: the level operator keeps them out (both limits = first edge index), the
     // residual scatters to their rows, the edge matrix gathers and scatters them (runtime.hip, EdgeMode).
     uint32_t gather_limit, scatter_limit;
+    FusedTransferDev<T, P> fused; // MODE_RESIDUAL_RESTRICT / MODE_CHEB_PROLONGATE only
   };
 
   // Interior-slot bookkeeping shared by the gather and the epilogue of lattice_apply_kernel: thread `tid`
@@ -1212,13 +1280,29 @@ namespace mgamd
   //     after    the VALUES of v' are requested (the registers of the sweeps are free again), then epilogue + atomics of v
   // so both round trips of the next gather overlap with work of the current slot.  D^-1 of interior DoFs always in closed
   // form (see lattice_apply_body): that is what frees the registers for the second set of gathered values.
-  template <typename T, int P, int B, int MODE, bool CONSTR = false>
+  //
+  // FUSED LEVEL TRANSFERS (MODE_RESIDUAL_RESTRICT, MODE_CHEB_PROLONGATE; ref:multigrid_throughput.cc:1600-1604 between
+  // Multigrid's residual / restriction and prolongation / post-smoothing steps).  The brick's 17-point lattice is the fine
+  // patch of the (B/2)^3 coarse cells under it, so the three embedding sweeps run on the lattice the operator holds in LDS:
+  //   RESTRICT    after the operator sweeps the lattice becomes  r = [interior: b - A x | shell: (owned ? b : 0) - this brick's
+  //               partial sum of A x], three transposed embedding sweeps reduce it in place to the 9^3 coarse lattice, which is
+  //               added to the coarse defect.  Restriction is linear: the partial sums of a shell row restricted by the bricks
+  //               that produced them add up to the row's restricted residual.  Neither t nor the tail accumulator is written.
+  //   PROLONGATE  before the operator sweeps the 9^3 coarse values are embedded on the scratch lattice and added to the gathered
+  //               x (shell entries that an un-fused patch owns arrive corrected already); x + P x_c is stored once (interior in
+  //               place, owned shell entries to a scratch vector that tail_kernel folds in) and never re-read by this pass.
+  // Slots that are not flagged as fused (no brick patch, halo slots of a sharded level) take the base mode's path.
+  template <typename T, int P, int B, int MODE_, bool CONSTR = false>
   __device__ __forceinline__ void
   lattice_apply_persistent_body(const ApplyArgs<T, P> &args, const uint32_t w, const uint32_t stride, unsigned char *smem_raw)
   {
     using G  = Geo<P, B>;
     using IM = InteriorMap<P, B>;
     static_assert(G::SPW == 1 && G::N_INT > 0, "persistent workgroups: one slot per workgroup");
+    constexpr int  MODE   = base_mode(MODE_);
+    constexpr bool FUSE_R = MODE_ == MODE_RESIDUAL_RESTRICT, FUSE_P = MODE_ == MODE_CHEB_PROLONGATE, FUSE = FUSE_R || FUSE_P;
+    static_assert(!FUSE || (!CONSTR && B >= 2 && G::ABLOCK == 256), "fused transfers: plain bricks, 256 threads");
+    constexpr int BC = B >= 2 ? B / 2 : 1, NC = P * BC + 1, NC3 = NC * NC * NC; // coarse lattice under the brick
     T *bufA = reinterpret_cast<T *>(smem_raw);
     T *bufB = bufA + G::N3;
     T *dtab = bufB + G::N3; // [P^3] s = d/h, [P^3] 1/s
@@ -1226,7 +1310,9 @@ namespace mgamd
     constexpr int BLOCK = G::ABLOCK;
     constexpr int ITER  = (G::N_INT + BLOCK - 1) / BLOCK;
     constexpr int ITERS = (G::N_SHELL + BLOCK - 1) / BLOCK;
+    constexpr int ITC   = FUSE ? (NC3 + BLOCK - 1) / BLOCK : 1;
     constexpr int P3    = P * P * P;
+    static_assert(!FUSE || 2 * ITERS <= 15, "two flag bits per shell entry in a 16-bit word");
 
     const int      tid = threadIdx.x;
     const uint32_t n   = args.g.n_slots;
@@ -1317,11 +1403,21 @@ namespace mgamd
     // doubles per thread).  Requested after the sweeps, or between the y and the x sweep, they fit whole-line sweeps but expose
     // their latency (measured: no gain over the one-workgroup-per-brick kernel).
     // slot tables of virtual block v
-    auto load_tables = [&](uint32_t v, uint32_t &slot, uint32_t &base, uint32_t(&sg)[ITERS], double &h, uint32_t &fm) {
+    auto load_tables = [&](uint32_t v, uint32_t &slot, uint32_t &base, uint32_t(&sg)[ITERS], double &h, uint32_t &fm, uint32_t &fl,
+                           uint32_t(&cg)[ITC]) {
       slot = xcd_contiguous(v, n);
       base = args.g.interior_base[slot];
       h    = args.g.h[slot];
       fm   = 0;
+      fl   = 0;
+      if constexpr (FUSE)
+        {
+          fl = args.fused.flags[(size_t)slot * BLOCK + tid];
+          const uint32_t *__restrict__ c0 = args.fused.coarse_idx + (size_t)slot * NC3;
+#pragma unroll
+          for (int it = 0; it < ITC; ++it)
+            cg[it] = NT_LOAD(c0 + min(tid + it * BLOCK, NC3 - 1));
+        }
       if constexpr (brick_may_be_constrained(B, CONSTR)) // the constraint mask travels with the tables (it was three exposed
         if (args.g.fmask != nullptr)                     // memory round trips per constrained brick when loaded where used)
           fm = args.g.fmask[slot];
@@ -1339,7 +1435,9 @@ namespace mgamd
         }
     };
     // operator input on the lattice of a slot (x_from_b: b and, on the shell, D^-1)
-    auto load_values = [&](uint32_t base, const uint32_t(&sg)[ITERS], T(&xv)[ITER], T(&sv)[ITERS], T(&sbv)[ITERS]) {
+    // (FUSE_R: sbv = b on the shell entries this brick owns; FUSE_P: cv = the coarse values under the brick)
+    auto load_values = [&](uint32_t base, const uint32_t(&sg)[ITERS], const uint32_t fl, const uint32_t(&cg)[ITC], T(&xv)[ITER], T(&sv)[ITERS],
+                           T(&sbv)[ITERS], T(&cv)[ITC]) {
       const T *__restrict__ in = x_from_b ? args.epi.b : args.src;
 #pragma unroll
       for (int it = 0; it < ITER; ++it)
@@ -1351,14 +1449,22 @@ namespace mgamd
           sv[it]            = in[gi];
           if (x_from_b)
             sbv[it] = args.epi.dinv[gi];
+          if (FUSE_R)
+            sbv[it] = args.epi.b[((fl >> (2 * it)) & 1u) ? gi : 0];
+        }
+      if constexpr (FUSE_P)
+        {
+#pragma unroll
+          for (int it = 0; it < ITC; ++it)
+            cv[it] = args.fused.coarse[cg[it] != DEV_INVALID ? cg[it] : 0];
         }
     };
 
-    uint32_t slot, base, sgi[ITERS], fmcur;
+    uint32_t slot, base, sgi[ITERS], fmcur, flcur, cgi[ITC];
     double   hcur;
-    T        xg[ITER], sval[ITERS], sb[ITERS];
-    load_tables(w, slot, base, sgi, hcur, fmcur);
-    load_values(base, sgi, xg, sval, sb);
+    T        xg[ITER], sval[ITERS], sb[ITERS], cval[ITC];
+    load_tables(w, slot, base, sgi, hcur, fmcur, flcur, cgi);
+    load_values(base, sgi, flcur, cgi, xg, sval, sb, cval);
 
     for (uint32_t v = w;;)
       {
@@ -1372,15 +1478,105 @@ namespace mgamd
         auto interior_dinv = [&](int t) -> T { // t: node type (InteriorWalk::type)
           return fabs((double)dtab[t]) > 1.0e-10 * fabs((double)rh) ? rh * dtab[P3 + t] : T(1);
         };
+        // one flag word per thread, bit 15 equal in all of them: a workgroup-uniform branch
+        const bool fused_slot = FUSE && ((__builtin_amdgcn_readfirstlane((int)flcur) >> 15) & 1);
+        T          bv[ITER], xo[ITER];
+        // ---- slot tables of the next slot, epilogue operands of this one: requested now ------------------------
+        uint32_t slotn = slot, basen = base, sgn[ITERS], fmn = fmcur, fln = flcur, cgn[ITC];
+        double   hn = hcur;
+        if (has_next)
+          load_tables(vn, slotn, basen, sgn, hn, fmn, fln, cgn);
+        {
+#pragma unroll
+          for (int it = 0; it < ITER; ++it)
+            {
+              const uint32_t g = base + (uint32_t)(has_entry(it) ? tid + it * BLOCK : 0);
+              xo[it]           = T(0);
+              bv[it]           = x_from_b ? xg[it] : T(0); // (x_from_b: x itself is recomputed in the epilogue: one value less across the sweeps)
+              if (MODE == MODE_CHEB && !FUSE_P && args.epi.xold) // (the fused prolongation pass has x_old = 0 by construction)
+                xo[it] = NT_LOAD(&args.epi.xold[g]);
+              if ((MODE == MODE_RESIDUAL || is_cheb(MODE)) && !x_from_b)
+                bv[it] = NT_LOAD(&args.epi.b[g]);
+            }
+        }
+        // ---- fused prolongation: x + P x_c on the lattice -----------------------------------------------------------
+        if constexpr (FUSE_P)
+          if (fused_slot)
+            {
+              // the coarse lattice at coordinates < NC of the scratch lattice, embedded in place z, y, x (a thread reads its line
+              // into registers before it writes it back; lines of one sweep are disjoint)
+#pragma unroll
+              for (int it = 0; it < ITC; ++it)
+                {
+                  const int idx = tid + it * BLOCK;
+                  if (idx < NC3)
+                    {
+                      const int x = idx % NC, y = (idx / NC) % NC, z = idx / (NC * NC);
+                      bufB[(z * G::N + y) * G::N + x] = cgi[it] != DEV_INVALID ? cval[it] : T(0);
+                    }
+                }
+              __syncthreads();
+              T cin[NC], cout[G::N];
+              for (int l = tid; l < NC * NC; l += BLOCK)
+                {
+                  const int b0 = (l / NC) * G::N + l % NC;
+#pragma unroll
+                  for (int i = 0; i < NC; ++i)
+                    cin[i] = bufB[b0 + i * G::N * G::N];
+                  line_embed<T, P, BC>(args.fused.E, cin, cout);
+#pragma unroll
+                  for (int i = 0; i < G::N; ++i)
+                    bufB[b0 + i * G::N * G::N] = cout[i];
+                }
+              __syncthreads();
+              for (int l = tid; l < NC * G::N; l += BLOCK)
+                {
+                  const int b0 = (l / NC) * G::N * G::N + l % NC;
+#pragma unroll
+                  for (int i = 0; i < NC; ++i)
+                    cin[i] = bufB[b0 + i * G::N];
+                  line_embed<T, P, BC>(args.fused.E, cin, cout);
+#pragma unroll
+                  for (int i = 0; i < G::N; ++i)
+                    bufB[b0 + i * G::N] = cout[i];
+                }
+              __syncthreads();
+              for (int l = tid; l < G::N * G::N; l += BLOCK)
+                {
+                  const int b0 = l * G::N;
+#pragma unroll
+                  for (int i = 0; i < NC; ++i)
+                    cin[i] = bufB[b0 + i];
+                  line_embed<T, P, BC>(args.fused.E, cin, cout);
+#pragma unroll
+                  for (int i = 0; i < G::N; ++i)
+                    bufB[b0 + i] = cout[i];
+                }
+              __syncthreads();
+              // x <- x + P x_c: shell entries owned by an un-fused patch are corrected already; this brick's own ones go to the
+              // scratch vector (tail_kernel folds them into x), the interior is stored in place
+#pragma unroll
+              for (int it = 0; it < ITERS; ++it)
+                if (spos[it] >= 0 && sgi[it] < args.gather_limit)
+                  {
+                    const uint32_t f2 = (flcur >> (2 * it)) & 3u;
+                    if (!(f2 & 2u))
+                      sval[it] += bufB[spos[it]];
+                    if (f2 & 1u)
+                      args.fused.scratch[sgi[it]] = sval[it];
+                  }
+              InteriorWalk wk = walk0;
+#pragma unroll
+              for (int it = 0; it < ITER; ++it, wk.next())
+                if (has_entry(it))
+                  {
+                    xg[it] += bufB[wk.pos()];
+                    NT_STORE(xg[it], &args.fused.x_inout[base + (uint32_t)(tid + it * BLOCK)]);
+                  }
+            }
         // ---- values of this slot -> LDS ---------------------------------------------------------------------
-        T bv[ITER], xo[ITER];
         if (x_from_b)
           {
-#pragma unroll
-            for (int it = 0; it < ITER; ++it)
-              {
-                bv[it] = xg[it]; // (x itself is recomputed in the epilogue: one value less across the sweeps)
-              }
 #pragma unroll
             for (int it = 0; it < ITERS; ++it)
               sval[it] = args.epi.c0 * sb[it] * sval[it];
@@ -1395,25 +1591,6 @@ namespace mgamd
           for (int it = 0; it < ITER; ++it, wk.next())
             if (has_entry(it))
               bufA[wk.pos()] = x_from_b ? args.epi.c0 * interior_dinv(wk.type()) * bv[it] : xg[it];
-        }
-        // ---- slot tables of the next slot, epilogue operands of this one: requested now ------------------------
-        uint32_t slotn = slot, basen = base, sgn[ITERS], fmn = fmcur;
-        double   hn = hcur;
-        if (has_next)
-          load_tables(vn, slotn, basen, sgn, hn, fmn);
-        {
-#pragma unroll
-          for (int it = 0; it < ITER; ++it)
-            {
-              const uint32_t g = base + (uint32_t)(has_entry(it) ? tid + it * BLOCK : 0);
-              xo[it]           = T(0);
-              if (!x_from_b)
-                bv[it] = T(0);
-              if (MODE == MODE_CHEB && args.epi.xold)
-                xo[it] = NT_LOAD(&args.epi.xold[g]);
-              if ((MODE == MODE_RESIDUAL || is_cheb(MODE)) && !x_from_b)
-                bv[it] = NT_LOAD(&args.epi.b[g]);
-            }
         }
         __syncthreads();
         MGAMD_STAMP(1)
@@ -1434,38 +1611,109 @@ namespace mgamd
         MGAMD_STAMP(2)
 
         // ---- values of the next slot: requested now, consumed at the top of the next iteration ------------------
-        T xgn[ITER], svaln[ITERS], sbn[ITERS];
+        T xgn[ITER], svaln[ITERS], sbn[ITERS], cvaln[ITC];
         if (has_next)
-          load_values(basen, sgn, xgn, svaln, sbn);
+          load_values(basen, sgn, fln, cgn, xgn, svaln, sbn, cvaln);
 
-        // ---- interior DoFs are complete: fused epilogue, contiguous stores -----------------------------------
-        InteriorWalk wk = walk0;
+        if (FUSE_R && fused_slot)
+          {
+            // ---- fused restriction: the lattice becomes this brick's part of b - A x, is reduced to the coarse lattice in
+            // place (x^T, y^T, z^T) and added to the coarse defect
+            if constexpr (FUSE_R)
+              {
+                InteriorWalk wk = walk0;
 #pragma unroll
-        for (int it = 0; it < ITER; ++it, wk.next())
-          if (has_entry(it))
-            {
-              const uint32_t g  = base + (uint32_t)(tid + it * BLOCK);
-              const T        ax = bufA[wk.pos()];
-              T              r;
-              if (MODE == MODE_VMULT)
-                r = ax;
-              else if (MODE == MODE_RESIDUAL)
-                r = bv[it] - ax;
-              else
+                for (int it = 0; it < ITER; ++it, wk.next())
+                  if (has_entry(it))
+                    bufA[wk.pos()] = bv[it] - bufA[wk.pos()];
+#pragma unroll
+                for (int it = 0; it < ITERS; ++it)
+                  if (spos[it] >= 0)
+                    bufA[spos[it]] = sgi[it] < args.scatter_limit ? (((flcur >> (2 * it)) & 1u) ? sb[it] : T(0)) - bufA[spos[it]] : T(0);
+                __syncthreads();
+                T rin[G::N], rout[NC];
+                for (int l = tid; l < G::N * G::N; l += BLOCK)
+                  {
+                    const int b0 = l * G::N;
+#pragma unroll
+                    for (int i = 0; i < G::N; ++i)
+                      rin[i] = bufA[b0 + i];
+                    line_embed_T<T, P, BC>(args.fused.E, rin, rout);
+#pragma unroll
+                    for (int i = 0; i < NC; ++i)
+                      bufA[b0 + i] = rout[i];
+                  }
+                __syncthreads();
+                for (int l = tid; l < NC * G::N; l += BLOCK)
+                  {
+                    const int b0 = (l / NC) * G::N * G::N + l % NC;
+#pragma unroll
+                    for (int i = 0; i < G::N; ++i)
+                      rin[i] = bufA[b0 + i * G::N];
+                    line_embed_T<T, P, BC>(args.fused.E, rin, rout);
+#pragma unroll
+                    for (int i = 0; i < NC; ++i)
+                      bufA[b0 + i * G::N] = rout[i];
+                  }
+                __syncthreads();
+                for (int l = tid; l < NC * NC; l += BLOCK)
+                  {
+                    const int b0 = (l / NC) * G::N + l % NC;
+#pragma unroll
+                    for (int i = 0; i < G::N; ++i)
+                      rin[i] = bufA[b0 + i * G::N * G::N];
+                    line_embed_T<T, P, BC>(args.fused.E, rin, rout);
+#pragma unroll
+                    for (int i = 0; i < NC; ++i)
+                      bufA[b0 + i * G::N * G::N] = rout[i];
+                  }
+                __syncthreads();
+#pragma unroll
+                for (int it = 0; it < ITC; ++it)
+                  {
+                    const int idx = tid + it * BLOCK;
+                    if (idx < NC3 && cgi[it] != DEV_INVALID)
+                      {
+                        const int x = idx % NC, y = (idx / NC) % NC, z = idx / (NC * NC);
+                        atomic_add(&args.fused.coarse[cgi[it]], bufA[(z * G::N + y) * G::N + x]);
+                      }
+                  }
+              }
+          }
+        else
+          {
+            // ---- interior DoFs are complete: fused epilogue, contiguous stores -----------------------------------
+            InteriorWalk wk = walk0;
+#pragma unroll
+            for (int it = 0; it < ITER; ++it, wk.next())
+              if (has_entry(it))
                 {
-                  const T dv  = interior_dinv(wk.type());
-                  const T xov = MODE == MODE_CHEB_SECOND ? args.epi.c0 * dv * bv[it] : xo[it];
-                  const T xv  = x_from_b ? args.epi.c0 * dv * bv[it] : xg[it];
-                  r           = xv + args.epi.f1 * (xv - xov) + args.epi.f2 * dv * (bv[it] - ax);
+                  const uint32_t g  = base + (uint32_t)(tid + it * BLOCK);
+                  const T        ax = bufA[wk.pos()];
+                  T              r;
+                  if (MODE == MODE_VMULT)
+                    r = ax;
+                  else if (MODE == MODE_RESIDUAL)
+                    r = bv[it] - ax;
+                  else
+                    {
+                      const T dv  = interior_dinv(wk.type());
+                      const T xov = MODE == MODE_CHEB_SECOND ? args.epi.c0 * dv * bv[it] : xo[it];
+                      const T xv  = x_from_b ? args.epi.c0 * dv * bv[it] : xg[it];
+                      if (FUSE_P)
+                        r = xv + args.epi.f2 * dv * (bv[it] - ax);
+                      else
+                        r = xv + args.epi.f1 * (xv - xov) + args.epi.f2 * dv * (bv[it] - ax);
+                    }
+                  NT_STORE(r, &args.epi.out[g]);
                 }
-              NT_STORE(r, &args.epi.out[g]);
-            }
-        MGAMD_STAMP(3)
-        // ---- shell DoFs: partial sums into the tail accumulator ------------------------------------------------
+            MGAMD_STAMP(3)
+            // ---- shell DoFs: partial sums into the tail accumulator ------------------------------------------------
 #pragma unroll
-        for (int it = 0; it < ITERS; ++it)
-          if (spos[it] >= 0 && sgi[it] < args.scatter_limit)
-            atomic_add(&args.tail_acc[sgi[it] - args.n_interior], bufA[spos[it]]);
+            for (int it = 0; it < ITERS; ++it)
+              if (spos[it] >= 0 && sgi[it] < args.scatter_limit)
+                atomic_add(&args.tail_acc[sgi[it] - args.n_interior], bufA[spos[it]]);
+          }
         MGAMD_STAMP(4)
         if (!has_next)
           break;
@@ -1474,6 +1722,13 @@ namespace mgamd
         base  = basen;
         hcur  = hn;
         fmcur = fmn;
+        flcur = fln;
+#pragma unroll
+        for (int it = 0; it < ITC; ++it)
+          {
+            cgi[it]  = cgn[it];
+            cval[it] = cvaln[it];
+          }
 #pragma unroll
         for (int it = 0; it < ITERS; ++it)
           {
@@ -1550,7 +1805,7 @@ namespace mgamd
         ApplyArgs<T, P> a = args.a;
         a.g               = args.g_constrained;
         a.stamps          = nullptr;
-        lattice_apply_persistent_body<T, P, B, MODE, true>(a, blockIdx.x, gridDim.x, smem_raw);
+        lattice_apply_persistent_body<T, P, B, base_mode(MODE), true>(a, blockIdx.x, gridDim.x, smem_raw);
         __syncthreads(); // the lattice of the last constrained brick has been read by every thread
         lattice_apply_persistent_body<T, P, B, MODE, false>(args.a, blockIdx.x, gridDim.x, smem_raw);
       }
@@ -1561,7 +1816,7 @@ namespace mgamd
         ApplyArgs<T, P> a = args.a;
         a.g               = args.g_constrained;
         a.stamps          = nullptr;
-        lattice_apply_persistent_body<T, P, B, MODE, true>(a, blockIdx.x - args.n_wg_plain, gridDim.x - args.n_wg_plain, smem_raw);
+        lattice_apply_persistent_body<T, P, B, base_mode(MODE), true>(a, blockIdx.x - args.n_wg_plain, gridDim.x - args.n_wg_plain, smem_raw);
       }
   }
 
@@ -1953,10 +2208,12 @@ namespace mgamd
 
   // Epilogue for the tail (accumulated shell sums) and the constrained DoFs (identity rows:
   // ref:include/operator.h:170-172); re-zeroes the accumulator for the next application.
-  template <typename T, int MODE>
+  template <typename T, int MODE_>
   __global__ void
   __launch_bounds__(256) tail_kernel(T *__restrict__ tail_acc, uint32_t n_interior, uint32_t n_tail, uint32_t n_rest, Epilogue<T> epi)
   {
+    constexpr int  MODE   = base_mode(MODE_); // (MODE_RESIDUAL_RESTRICT: plain residual rows for the un-fused restriction)
+    constexpr bool FUSE_P = MODE_ == MODE_CHEB_PROLONGATE;
     constexpr int  U      = 4;
     const uint32_t total  = n_tail + n_rest;
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -1979,7 +2236,15 @@ namespace mgamd
             if (i < total)
               {
                 if (MODE != MODE_INVDIAG && MODE != MODE_CHEB_FIRST && (is_cheb(MODE) || i >= n_tail))
-                  xv[u] = NT_LOAD(&epi.x[gi]);
+                  {
+                    if (FUSE_P && i < n_tail && NT_LOAD(&epi.xs_flag[i]))
+                      { // x + P x_c as the owning fused brick left it: folded into x here, after every brick has gathered x
+                        xv[u] = NT_LOAD(&epi.xs[gi]);
+                        epi.x_inout[gi] = xv[u];
+                      }
+                    else
+                      xv[u] = NT_LOAD(&epi.x[gi]);
+                  }
                 ax[u] = i < n_tail ? tail_acc[i] : xv[u];
                 if (MODE == MODE_RESIDUAL || is_cheb(MODE))
                   bv[u] = NT_LOAD(&epi.b[gi]);
@@ -2530,40 +2795,6 @@ namespace mgamd
     const T        *src;
     T              *dst;
   };
-
-  // fine line (P*BC*2+1) from coarse line (P*BC+1), cell by cell
-  template <typename T, int P, int BC>
-  __device__ __forceinline__ void
-  line_embed(const double *__restrict__ E, const T (&in)[P * BC + 1], T (&out)[2 * P * BC + 1])
-  {
-#pragma unroll
-    for (int c = 0; c < BC; ++c)
-#pragma unroll
-      for (int a = (c == 0 ? 0 : 1); a <= 2 * P; ++a)
-        {
-          T s = T(0);
-#pragma unroll
-          for (int b = 0; b <= P; ++b)
-            s += T(E[a * (P + 1) + b]) * in[c * P + b];
-          out[c * 2 * P + a] = s;
-        }
-  }
-  // transpose: coarse line += E^T fine line; fine nodes shared by two coarse cells are counted once
-  template <typename T, int P, int BC>
-  __device__ __forceinline__ void
-  line_embed_T(const double *__restrict__ E, const T (&in)[2 * P * BC + 1], T (&out)[P * BC + 1])
-  {
-#pragma unroll
-    for (int i = 0; i < P * BC + 1; ++i)
-      out[i] = T(0);
-#pragma unroll
-    for (int c = 0; c < BC; ++c)
-#pragma unroll
-      for (int a = (c == 0 ? 0 : 1); a <= 2 * P; ++a)
-#pragma unroll
-        for (int b = 0; b <= P; ++b)
-          out[c * P + b] += T(E[a * (P + 1) + b]) * in[c * 2 * P + a];
-  }
 
   template <typename T, int P, int B>
   __global__ void

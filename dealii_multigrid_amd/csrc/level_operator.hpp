@@ -245,6 +245,28 @@ namespace mgamd
     }
   };
 
+  // Host view of the level transfers fused into the operator passes of the FINE level (Transfer2 owns the tables; kernels.hpp,
+  // FusedTransferDev): the bricks of slot group `group` flagged in `flags` restrict / prolongate inside the persistent kernel.
+  template <typename T>
+  struct FusedTransferHost
+  {
+    int                 group = -1;
+    const uint16_t     *flags = nullptr;      // [n_slots of the group][256]
+    const uint32_t     *coarse_idx = nullptr; // [n_slots of the group][nc3]
+    uint32_t            nc3 = 0;
+    std::vector<double> E;                    // 1D h-embedding (2p+1) x (p+1)
+    const uint8_t      *tail_flags = nullptr; // [n_tail]: the tail DoF is owned by a fused brick
+    // per call
+    T *coarse = nullptr, *scratch = nullptr, *x_inout = nullptr;
+  };
+  // degrees whose 17-point lattice kernel carries the fused modes (p = 3 has 13-point lattices, one workgroup per brick)
+  template <typename T>
+  inline bool
+  fused_transfer_supported(int p)
+  {
+    return (p == 1 && use_persistent<T, 1>()) || (p == 2 && use_persistent<T, 2>()) || (p == 4 && use_persistent<T, 4>());
+  }
+
   template <typename T>
   struct LevelOperator : LevelOperatorBase
   {
@@ -498,18 +520,64 @@ namespace mgamd
             HIP_CHECK(hipGetLastError());
             return;
           }
-      auto           kern   = lattice_apply_pair_kernel<T, P, B, MODE>;
-      ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), lds);
-      hipLaunchKernelGGL(kern, pa.n_wg_plain + n_wg_c, G::ABLOCK, lds, st, pa);
-      HIP_CHECK(hipGetLastError());
+      if constexpr (MODE != base_mode(MODE))
+        throw std::runtime_error("fused transfers need the persistent brick kernel");
+      else
+        {
+          auto kern = lattice_apply_pair_kernel<T, P, B, MODE>;
+          ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), lds);
+          hipLaunchKernelGGL(kern, pa.n_wg_plain + n_wg_c, G::ABLOCK, lds, st, pa);
+          HIP_CHECK(hipGetLastError());
+        }
     }
 
+    // the 17-point lattice group that carries fused transfers (slots [begin, begin + a.g.n_slots) of it)
     template <int P, int MODE>
     void
-    launch_group(hipStream_t st, ApplyArgs<T, P> &a, GroupDev<T> *g, GroupDev<T> *partner_cells, GroupDev<T> *partner_clusters,
-                 const T *src, const Epilogue<T> &epi, bool diag, size_t begin, size_t end, GroupDev<T> *partner_constrained = nullptr)
+    launch_fused(hipStream_t st, ApplyArgs<T, P> &a, size_t begin, GroupDev<T> *partner_constrained, const FusedTransferHost<T> &f)
     {
+      if constexpr (P == 1 || P == 2 || P == 4)
+        {
+          constexpr int B = 16 / P;
+          using G         = Geo<P, B>;
+          constexpr int NC = P * B / 2 + 1, NC3 = NC * NC * NC;
+          if (f.nc3 != (uint32_t)NC3 || f.E.size() != (size_t)(2 * P + 1) * (P + 1) || !use_persistent<T, P>())
+            throw std::runtime_error("fused transfer: tables do not match the brick kernel");
+          a.fused.flags      = f.flags + begin * G::ABLOCK;
+          a.fused.coarse_idx = f.coarse_idx + begin * NC3;
+          for (size_t i = 0; i < f.E.size(); ++i)
+            a.fused.E[i] = f.E[i];
+          a.fused.coarse  = f.coarse;
+          a.fused.x_inout = f.x_inout;
+          a.fused.scratch = f.scratch;
+          if (partner_constrained)
+            {
+              if constexpr (P == 1)
+                return launch_pair<P, B, MODE>(st, a, partner_constrained);
+              throw std::runtime_error("brick pair launch: size not instantiated");
+            }
+          const size_t lds      = (2 * (size_t)G::N3 + 2 * P * P * P + 1) * sizeof(T);
+          const int    resident = resident_workgroups(ctx);
+          auto         kern     = lattice_apply_persistent_kernel<T, P, B, MODE>;
+          ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), lds);
+          hipLaunchKernelGGL(kern, std::min((int)a.g.n_slots, resident), G::ABLOCK, lds, st, a);
+          HIP_CHECK(hipGetLastError());
+        }
+      else
+        throw std::runtime_error("fused transfers: degree without 17-point lattice kernel");
+    }
+
+    template <int P, int MODE_>
+    void
+    launch_group(hipStream_t st, ApplyArgs<T, P> &a, GroupDev<T> *g, GroupDev<T> *partner_cells, GroupDev<T> *partner_clusters,
+                 const T *src, const Epilogue<T> &epi, bool diag, size_t begin, size_t end, GroupDev<T> *partner_constrained = nullptr,
+                 const FusedTransferHost<T> *fused = nullptr)
+    {
+      constexpr int MODE = base_mode(MODE_); // every group but the fused one runs the base mode of a fused pass
       a.g      = (begin == 0 && end == g->n_slots) ? g->view() : g->view(begin, end);
+      if constexpr (MODE_ != MODE)
+        if (fused && fused->group >= 0 && g == groups[fused->group].get())
+          return launch_fused<P, MODE_>(st, a, begin, partner_constrained, *fused);
       if (partner_constrained)
         {
           if constexpr (P == 1)
@@ -599,25 +667,33 @@ namespace mgamd
     // defined in level_operator_apply.hpp, instantiated in apply_inst.hip (one translation unit per number type and degree)
     template <int P, int MODE>
     void
-    apply_P(const T *src, const Epilogue<T> &epi, bool diag, double words, int edge_mode);
+    apply_P(const T *src, const Epilogue<T> &epi, bool diag, double words, int edge_mode, const FusedTransferHost<T> *fused);
 
     template <int MODE>
     void
-    apply(const T *src, const Epilogue<T> &epi, bool diag = false, double words = 0, int edge_mode = EDGE_OUT)
+    apply(const T *src, const Epilogue<T> &epi, bool diag = false, double words = 0, int edge_mode = EDGE_OUT,
+          const FusedTransferHost<T> *fused = nullptr)
     {
+      constexpr bool FUSED_MODE = MODE != base_mode(MODE);
+      if (FUSED_MODE && (!fused || fused->group < 0 || !fused_transfer_supported<T>(p)))
+        throw std::runtime_error("fused transfer pass without fused tables");
       switch (p)
         {
           case 1:
-            apply_P<1, MODE>(src, epi, diag, words, edge_mode);
+            apply_P<1, MODE>(src, epi, diag, words, edge_mode, fused);
             break;
           case 2:
-            apply_P<2, MODE>(src, epi, diag, words, edge_mode);
+            apply_P<2, MODE>(src, epi, diag, words, edge_mode, fused);
             break;
           case 3:
-            apply_P<3, MODE>(src, epi, diag, words, edge_mode);
+            if constexpr (!FUSED_MODE)
+              apply_P<3, MODE>(src, epi, diag, words, edge_mode, fused);
             break;
           case 4:
-            apply_P<4, MODE>(src, epi, diag, words, edge_mode);
+            if constexpr (FUSED_MODE && std::is_same<T, float>::value)
+              throw std::runtime_error("fused transfers: not instantiated for float at p = 4");
+            else
+              apply_P<4, MODE>(src, epi, diag, words, edge_mode, fused);
             break;
           default:
             throw std::runtime_error("degree not instantiated");
@@ -735,6 +811,25 @@ namespace mgamd
         apply<MODE_CHEB_SECOND>(x, e, false, 4.0);
       else
         apply<MODE_CHEB>(x, e, false, xold ? 5.0 : 4.0);
+    }
+
+    // first pass of a smoothing step (x_old = 0, f1 = 0) on x + P x_c with the prolongation fused into the brick kernel
+    // (kernels.hpp MODE_CHEB_PROLONGATE): x is updated in place to x + P x_c, f.scratch is clobbered on the tail
+    void
+    cheb_prolongate_raw(T *out, T *x, const T *b, const T *dinv, double f2, const FusedTransferHost<T> &f_in)
+    {
+      FusedTransferHost<T> f = f_in;
+      f.x_inout              = x;
+      Epilogue<T> e{out, x, nullptr, b, dinv, T(0), T(f2), T(0)};
+      if (dinv == dinv_coded && dinv_code.p)
+        {
+          e.dinv_code  = dinv_code.p;
+          e.dinv_table = dinv_table.p;
+        }
+      e.xs_flag = f.tail_flags;
+      e.xs      = f.scratch;
+      e.x_inout = x;
+      apply<MODE_CHEB_PROLONGATE>(x, e, false, 4.0, EDGE_OUT, &f);
     }
 
     void

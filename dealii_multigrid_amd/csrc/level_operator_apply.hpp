@@ -8,8 +8,9 @@ namespace mgamd
   template <typename T>
   template <int P, int MODE>
   void
-  LevelOperator<T>::apply_P(const T *src, const Epilogue<T> &epi, bool diag, double words, int edge_mode)
+  LevelOperator<T>::apply_P(const T *src, const Epilogue<T> &epi, bool diag, double words, int edge_mode, const FusedTransferHost<T> *fused)
   {
+    constexpr int BASE = base_mode(MODE);
     ApplyArgs<T, P> a;
     const uint32_t  first_edge = tables->n_interior + tables->n_tail;
     a.gather_limit  = first_edge + (edge_mode == EDGE_IN ? tables->n_edge : 0);
@@ -60,12 +61,18 @@ namespace mgamd
           if (begin >= end)
             return;
           if (P == 1 && g->has_clusters())
-            launch_clusters(ctx->stream, *g, src, epi, MODE == MODE_CHEB_FIRST, (uint32_t)(begin / CLUSTER_CELLS),
+            launch_clusters(ctx->stream, *g, src, epi, BASE == MODE_CHEB_FIRST, (uint32_t)(begin / CLUSTER_CELLS),
                             (uint32_t)((end + CLUSTER_CELLS - 1) / CLUSTER_CELLS));
           else
             {
               a.g = g->view(begin, end);
-              dispatch_B<T, P, MODE>(ctx, ctx->stream, g->B, g->constrained, a, diag);
+              if (MODE != BASE && fused && fused->group >= 0 && g == groups[fused->group].get())
+                {
+                  if constexpr (MODE != BASE)
+                    launch_fused<P, MODE>(ctx->stream, a, begin, nullptr, *fused);
+                }
+              else
+                dispatch_B<T, P, BASE>(ctx, ctx->stream, g->B, g->constrained, a, diag);
             }
         };
         size_t n_interior_slots = 0;
@@ -144,7 +151,7 @@ namespace mgamd
           }
         const bool prof = prof_begin(*g);
         launch_group<P, MODE>(main, a, g, (merged && g == g2) ? g1 : nullptr, (merged_p1 && g == g8) ? gc : nullptr, src, epi, diag, 0,
-                              g->n_slots, constrained_partner(g));
+                              g->n_slots, constrained_partner(g), fused);
         if (prof)
           prof_end(*g, g->n_slots);
       }

@@ -503,12 +503,16 @@ namespace mgamd
         hipLaunchKernelGGL((vec_copy_kernel<T, T>), grid_for(n), 256, 0, ctx->stream, S, cur, n);
     }
 
-    // general initial guess x0 in X; O is scratch; returns the buffer holding the result
+    // general initial guess x0 in X; O is scratch; returns the buffer holding the result.  prolongate != nullptr: the initial
+    // guess is X + P x_c with the prolongation fused into the first operator pass (X becomes X + P x_c on the way)
     T *
-    step_raw(T *X, T *O, const T *b)
+    step_raw(T *X, T *O, const T *b, const FusedTransferHost<T> *prolongate = nullptr)
     {
       T *cur = X, *oth = O;
-      lop->cheb_raw(oth, cur, nullptr, b, dinv.p, 0.0, 1.0 / theta);
+      if (prolongate)
+        lop->cheb_prolongate_raw(oth, cur, b, dinv.p, 1.0 / theta, *prolongate);
+      else
+        lop->cheb_raw(oth, cur, nullptr, b, dinv.p, 0.0, 1.0 / theta);
       std::swap(cur, oth);
       if (degree >= 2 && std::fabs(delta) >= 1e-40)
         {
@@ -613,8 +617,27 @@ namespace mgamd
     {
       int            B = 2, fine_group = 0;
       size_t         n_bricks = 0;
+      size_t         n_unfused = 0; // fused group: the bricks [n_unfused, n_bricks) are transferred inside the operator passes
+      bool           fused = false;
       DBuf<uint32_t> slot, coarse_idx, own_shell, own_shell_restrict;
     };
+    // Transfers fused into the fine level's operator passes (kernels.hpp MODE_RESIDUAL_RESTRICT / MODE_CHEB_PROLONGATE): tables by
+    // SLOT of the fused group.  MGAMD_NO_FUSED_TRANSFER=1 disables them (development A/B; same results up to rounding).
+    FusedTransferHost<T> fused;
+    DBuf<uint16_t>       fused_flags;
+    DBuf<uint32_t>       fused_coarse_idx;
+    DBuf<uint8_t>        fused_tail_flags;
+    size_t               n_fused_bricks = 0;
+    bool
+    fused_ready() const
+    {
+      return fused.group >= 0 && n_fused_bricks > 0;
+    }
+    uint64_t
+    n_fused_bricks_total() const override
+    {
+      return fused_ready() ? n_fused_bricks : 0;
+    }
     GroupD                               grp[3];
     std::vector<std::unique_ptr<BrickD>> bricks;
     LevelOperator<T>                    *fop = nullptr, *cop = nullptr;
@@ -630,8 +653,20 @@ namespace mgamd
       fop    = f;
       cop    = c;
       ctx    = f->ctx;
-      const char    *nb = getenv("MGAMD_NO_BRICK_TRANSFER");
-      TransferTables tt(*f->tables, *c->tables, !(nb && atoi(nb)));
+      const char *nb         = getenv("MGAMD_NO_BRICK_TRANSFER");
+      const bool  use_bricks = !(nb && atoi(nb));
+      // the fine group whose bricks carry the fused transfers: the plain 17-point lattices of an h-transfer, if the level's
+      // operator runs them with persistent workgroups; not on local-smoothing levels (edge rows, partial coverage)
+      int fuse_group = -1;
+      if (use_bricks && !getenv("MGAMD_NO_FUSED_TRANSFER") && f->tables->tria != c->tables->tria && f->tables->p == c->tables->p &&
+          !f->tables->ls_level && !c->tables->ls_level && fused_transfer_supported<T>(f->tables->p))
+        for (size_t gi = 0; gi < f->tables->groups.size(); ++gi)
+          {
+            const SlotGroup &g = f->tables->groups[gi];
+            if (g.N == 17 && !g.constrained_group && g.n_slots() > 0)
+              fuse_group = (int)gi;
+          }
+      TransferTables tt(*f->tables, *c->tables, use_bricks, fuse_group);
       // sharded fine level: a residual entry that is a copy of another rank's DoF is restricted by its owner only
       const uint32_t copy_lo = f->tables->n_interior + f->tables->n_tail_owned, copy_hi = f->tables->n_interior + f->tables->n_tail;
       auto           owned_only = [&](std::vector<uint32_t> v) {
@@ -646,6 +681,36 @@ namespace mgamd
           d->B          = bg.B;
           d->fine_group = bg.fine_group;
           d->n_bricks   = bg.n_bricks();
+          d->n_unfused  = bg.fused ? bg.n_unfused : bg.n_bricks();
+          d->fused      = bg.fused;
+          if (bg.fused && bg.n_bricks() > bg.n_unfused)
+            {
+              const SlotGroup &fg  = f->tables->groups[bg.fine_group];
+              const size_t     ns  = fg.n_slots(), nsh = (size_t)fg.n_shell, nc3 = (size_t)bg.Nc * bg.Nc * bg.Nc;
+              if (2 * ((nsh + 255) / 256) > 15)
+                throw std::runtime_error("fused transfer: shell too large for the flag word");
+              std::vector<uint16_t> fl(ns * 256, 0);
+              std::vector<uint32_t> ci(ns * nc3, INVALID_DOF);
+              for (size_t q = bg.n_unfused; q < bg.n_bricks(); ++q)
+                {
+                  const size_t sl = bg.slot[q];
+                  for (size_t t = 0; t < 256; ++t)
+                    fl[sl * 256 + t] = 0x8000u;
+                  for (size_t t = 0; t < nsh; ++t)
+                    fl[sl * 256 + t % 256] |= (uint16_t)((bg.shell_flags[q * nsh + t] & 3u) << (2 * (t / 256)));
+                  std::copy(bg.coarse_idx.begin() + q * nc3, bg.coarse_idx.begin() + (q + 1) * nc3, ci.begin() + sl * nc3);
+                }
+              fused_flags.upload(fl);
+              fused_coarse_idx.upload(ci);
+              fused_tail_flags.upload(tt.tail_owned_by_fused);
+              fused.group      = bg.fine_group;
+              fused.flags      = fused_flags.p;
+              fused.coarse_idx = fused_coarse_idx.p;
+              fused.nc3        = (uint32_t)nc3;
+              fused.E          = fec.embedding(1, f->tables->p);
+              fused.tail_flags = fused_tail_flags.p;
+              n_fused_bricks   = bg.n_bricks() - bg.n_unfused;
+            }
           d->slot.upload(bg.slot);
           d->coarse_idx.upload(bg.coarse_idx);
           d->own_shell.upload(bg.own_shell);
@@ -742,10 +807,13 @@ namespace mgamd
       HIP_CHECK(hipGetLastError());
     }
 
+    // the first n_launch bricks of the group (all of them, or the un-fused ones of a fused group)
     template <int P, int B>
     void
-    launch_brick(const BrickD &b, const T *src, T *dst, bool prolongate)
+    launch_brick(const BrickD &b, const T *src, T *dst, bool prolongate, size_t n_launch)
     {
+      if (n_launch == 0)
+        return;
       using G = BrickTransferGeo<P, B>;
       BrickTransferArgs<T, P> a;
       const GroupDev<T>      &fg = *fop->groups[b.fine_group];
@@ -754,7 +822,7 @@ namespace mgamd
       a.shell_pos     = fg.shell_pos.p;
       a.coarse_idx    = b.coarse_idx.p;
       a.own_shell     = (!prolongate && b.own_shell_restrict.p) ? b.own_shell_restrict.p : b.own_shell.p;
-      a.n_bricks      = (uint32_t)b.n_bricks;
+      a.n_bricks      = (uint32_t)n_launch;
       const std::vector<double> E = fec.embedding(1, P);
       for (int i = 0; i < (2 * P + 1) * (P + 1); ++i)
         a.E[i] = E[i];
@@ -765,7 +833,7 @@ namespace mgamd
         {
           auto kern = brick_prolongate_kernel<T, P, B>;
           ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), lds);
-          hipLaunchKernelGGL(kern, (int)b.n_bricks, G::BLOCK, lds, ctx->stream, a);
+          hipLaunchKernelGGL(kern, (int)n_launch, G::BLOCK, lds, ctx->stream, a);
         }
       else if (G::NF == 17 && getenv("MGAMD_NO_PERSISTENT") == nullptr)
         {
@@ -775,65 +843,69 @@ namespace mgamd
               auto kern = brick_restrict_persistent_kernel<T, P, B>;
               ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), lds);
               const int resident = std::max(8, 3 * ctx->n_cu / 8 * 8);
-              hipLaunchKernelGGL(kern, std::min((int)b.n_bricks, resident), G::BLOCK, lds, ctx->stream, a);
+              hipLaunchKernelGGL(kern, std::min((int)n_launch, resident), G::BLOCK, lds, ctx->stream, a);
             }
         }
       else
         {
           auto kern = brick_restrict_kernel<T, P, B>;
           ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), lds);
-          hipLaunchKernelGGL(kern, (int)b.n_bricks, G::BLOCK, lds, ctx->stream, a);
+          hipLaunchKernelGGL(kern, (int)n_launch, G::BLOCK, lds, ctx->stream, a);
         }
       HIP_CHECK(hipGetLastError());
     }
 
     template <int P>
     void
-    dispatch_brick(const BrickD &b, const T *src, T *dst, bool prolongate)
+    dispatch_brick(const BrickD &b, const T *src, T *dst, bool prolongate, size_t n_launch)
     {
       switch (b.B)
         {
           case 2:
             if constexpr (P * 2 + 1 <= 17)
-              return launch_brick<P, 2>(b, src, dst, prolongate);
+              return launch_brick<P, 2>(b, src, dst, prolongate, n_launch);
             break;
           case 4:
             if constexpr (P * 4 + 1 <= 17)
-              return launch_brick<P, 4>(b, src, dst, prolongate);
+              return launch_brick<P, 4>(b, src, dst, prolongate, n_launch);
             break;
           case 8:
             if constexpr (P * 8 + 1 <= 17)
-              return launch_brick<P, 8>(b, src, dst, prolongate);
+              return launch_brick<P, 8>(b, src, dst, prolongate, n_launch);
             break;
           case 16:
             if constexpr (P * 16 + 1 <= 17)
-              return launch_brick<P, 16>(b, src, dst, prolongate);
+              return launch_brick<P, 16>(b, src, dst, prolongate, n_launch);
             break;
         }
       throw std::runtime_error("brick transfer: unsupported brick size");
     }
 
+    // skip_fused: leave out the bricks whose transfer happens inside the operator passes
     void
-    run(const T *src, T *dst, bool prolongate)
+    run(const T *src, T *dst, bool prolongate, bool skip_fused = false)
     {
       for (auto &b : bricks)
-        switch (pc)
+        {
+          const size_t nb = skip_fused ? b->n_unfused : b->n_bricks;
+          switch (pc)
           {
             case 1:
-              dispatch_brick<1>(*b, src, dst, prolongate);
+              dispatch_brick<1>(*b, src, dst, prolongate, nb);
               break;
             case 2:
-              dispatch_brick<2>(*b, src, dst, prolongate);
+              dispatch_brick<2>(*b, src, dst, prolongate, nb);
               break;
             case 3:
-              dispatch_brick<3>(*b, src, dst, prolongate);
+              dispatch_brick<3>(*b, src, dst, prolongate, nb);
               break;
             case 4:
-              dispatch_brick<4>(*b, src, dst, prolongate);
+              dispatch_brick<4>(*b, src, dst, prolongate, nb);
               break;
             default:
               throw std::runtime_error("brick transfer: degree not instantiated");
           }
+        }
       for (int k = 0; k < 3; ++k)
         {
           const GroupD &g = grp[k];
@@ -885,6 +957,33 @@ namespace mgamd
         }
     }
 
+    // Fused passes (fused_ready()): the residual step and the restriction of Multigrid::level_v_step in ONE operator pass
+    // (ref:multigrid_throughput.cc:1093-1099 wiring; deal.II level_v_step: residual, restrict_and_add).  t receives the residual
+    // rows that the un-fused patches still restrict (everything outside the fused bricks); the coarse defect receives the fused
+    // bricks' part directly.  Call restrict_unfused_raw afterwards.
+    void
+    residual_restrict_raw(T *dst_coarse, T *t, const T *b, const T *x)
+    {
+      FusedTransferHost<T> f = fused;
+      f.coarse               = dst_coarse;
+      Epilogue<T> e{t, x, nullptr, b, nullptr, T(0), T(0), T(0)};
+      fop->template apply<MODE_RESIDUAL_RESTRICT>(x, e, false, 0, 0, &f);
+    }
+    void
+    restrict_unfused_raw(T *dst_coarse, const T *src_fine)
+    {
+      run(src_fine, dst_coarse, false, true);
+      finish_restriction(dst_coarse);
+    }
+    // the un-fused part of the prolongation (in place); the fused bricks add theirs while the first post-smoothing pass
+    // gathers x (Chebyshev::step_raw with this transfer)
+    void
+    prolongate_unfused_raw(T *dst_fine, const T *src_coarse)
+    {
+      run(src_coarse, dst_fine, true, true);
+      if (fop->halo)
+        fop->import_from_owner_raw(dst_fine + fop->tables->n_interior);
+    }
     void
     prolongate_raw(T *dst_fine, const T *src_coarse)
     {
@@ -898,6 +997,11 @@ namespace mgamd
     restrict_raw(T *dst_coarse, const T *src_fine)
     {
       run(src_fine, dst_coarse, false);
+      finish_restriction(dst_coarse);
+    }
+    void
+    finish_restriction(T *dst_coarse)
+    {
       // sharded runs: complete the coarse defect across ranks
       if (cop->halo)
         cop->exchange_add_raw(dst_coarse + cop->tables->n_interior);
@@ -957,6 +1061,7 @@ namespace mgamd
     unsigned     collapse_level = 0;
     DBuf<double> collapse_M;
     bool         collapse_enabled = true;
+    bool         fuse_transfers   = true; // level transfers inside the operator passes where the transfer offers them
     unsigned
     set_collapse(bool on) override
     {
@@ -1354,18 +1459,31 @@ namespace mgamd
           sol[l] = sview[l];
           return;
         }
+      // level transfers inside the operator passes (Transfer2::fused_ready; not while stage callbacks want the reference's
+      // separate stages): stage 1 is then residual + fused restriction, stage 2 the restriction of the remaining patches, stage 4
+      // the un-fused prolongation, and the fused prolongation is part of the first post-smoothing pass (stage 6)
+      const bool fuse = fuse_transfers && !cb && tr[l]->fused_ready();
       stage(0, true, l);
       sm[l]->vmult_raw(sview[l], tview[l], dview[l]); // pre-smoothing, zero start
       stage(0, false, l);
       stage(1, true, l);
-      ops[l]->residual_raw(res[l]->p, dview[l], sview[l]); // t = d - A x
+      if (fuse)
+        tr[l]->residual_restrict_raw(dptr[l - 1], res[l]->p, dview[l], sview[l]);
+      else
+        ops[l]->residual_raw(res[l]->p, dview[l], sview[l]); // t = d - A x
       stage(1, false, l);
       stage(2, true, l);
-      tr[l]->restrict_raw(dptr[l - 1], res[l]->p);
+      if (fuse)
+        tr[l]->restrict_unfused_raw(dptr[l - 1], res[l]->p);
+      else
+        tr[l]->restrict_raw(dptr[l - 1], res[l]->p);
       stage(2, false, l);
       level_v_step(l - 1);
       stage(4, true, l);
-      tr[l]->prolongate_raw(sview[l], sol[l - 1]);
+      if (fuse)
+        tr[l]->prolongate_unfused_raw(sview[l], sol[l - 1]);
+      else
+        tr[l]->prolongate_raw(sview[l], sol[l - 1]);
       stage(4, false, l);
       stage(5, true, l); // edge_prolongation: no-op for global coarsening (ref:multigrid_throughput.cc:1126-1130)
       if (ops[l]->tables->n_edge)
@@ -1378,7 +1496,15 @@ namespace mgamd
         }
       stage(5, false, l);
       stage(6, true, l);
-      sol[l] = sm[l]->step_raw(sview[l], tview[l], dview[l]); // post-smoothing
+      if (fuse)
+        {
+          FusedTransferHost<T> f = tr[l]->fused;
+          f.coarse               = sol[l - 1];
+          f.scratch              = res[l]->p; // the residual vector is free again
+          sol[l]                 = sm[l]->step_raw(sview[l], tview[l], dview[l], &f);
+        }
+      else
+        sol[l] = sm[l]->step_raw(sview[l], tview[l], dview[l]); // post-smoothing
       stage(6, false, l);
     }
 

@@ -223,6 +223,9 @@ namespace mgamd
     prolongate_and_add(mgamd_vec &dst_fine, const mgamd_vec &src_coarse) = 0;
     virtual void
     restrict_and_add(mgamd_vec &dst_coarse, const mgamd_vec &src_fine) = 0;
+    // bricks of the fine level whose part of this transfer can run inside the level operator's passes (0: none)
+    virtual uint64_t
+    n_fused_bricks_total() const = 0;
   };
 
   struct MultigridBase

@@ -39,6 +39,18 @@ namespace mgamd
     std::vector<uint32_t> slot;        // fine slot index within its group
     std::vector<uint32_t> coarse_idx;  // per brick x Nc^3 (resolved, INVALID = Dirichlet)
     std::vector<uint32_t> own_shell;   // per brick x n_shell: fine shell DoF if this brick owns it, else INVALID
+    // Transfers FUSED into the operator passes (kernels.hpp, MODE_RESIDUAL_RESTRICT / MODE_CHEB_PROLONGATE): the bricks
+    // [n_unfused, n_bricks) of this group do their restriction / prolongation inside the level operator's brick kernel.
+    // Ownership is then assigned so that every DoF touched by ANY slot outside the fused set belongs to a patch outside the
+    // fused set (those patches claim first); per shell entry of a fused brick:
+    //   SHELL_OWN    this brick owns the DoF: it adds b_i to the restricted residual and stores x_i + (P x_c)_i
+    //   SHELL_OTHER  an un-fused patch owns it: its residual travels through the tail accumulator, and the un-fused
+    //                prolongation has already corrected x_i when the fused pass gathers it
+    //   0            another fused brick owns it (a brick still restricts ITS partial sum and adds the correction to its copy)
+    static constexpr uint8_t SHELL_OWN = 1, SHELL_OTHER = 2;
+    size_t                   n_unfused = 0;
+    bool                     fused     = false;
+    std::vector<uint8_t>     shell_flags; // per brick x n_shell (fused groups only; zero rows for the un-fused bricks)
     size_t
     n_bricks() const
     {
@@ -52,8 +64,12 @@ namespace mgamd
     int                             pc = 1, pf = 1;
     TransferGroup                   groups[3];
     std::vector<BrickTransferGroup> bricks; // only with use_bricks
+    // fused transfers (fuse_group >= 0): tail DoFs (index - n_interior) owned by a fused brick
+    std::vector<uint8_t> tail_owned_by_fused;
 
-    TransferTables(const LevelTables &fine, const LevelTables &coarse, bool use_bricks = false)
+    // fuse_group: fine slot group whose bricks take part in the fused transfers (-1: none); on a sharded fine level its halo
+    // slots (the first n_halo_slots, which touch DoFs shared with other ranks) stay un-fused
+    TransferTables(const LevelTables &fine, const LevelTables &coarse, bool use_bricks = false, int fuse_group = -1)
       : pc(coarse.p)
       , pf(fine.p)
     {
@@ -68,6 +84,31 @@ namespace mgamd
         throw std::runtime_error("transfer: simultaneous h- and p-coarsening is not supported");
       std::vector<bool> claimed(fine.n_dofs, false);
       std::vector<bool> covered(tc.cells.size(), false); // coarse cells handled by a brick patch
+      // claims of one brick: interior DoFs are owned by construction, free shell DoFs are claimed if nobody owns them yet
+      auto claim_brick = [&](BrickTransferGroup &bg, const SlotGroup &fg, size_t s, const std::vector<bool> *before, uint8_t *flags) {
+        for (int t = 0; t < fg.n_interior; ++t)
+          claimed[fg.interior_base[s] + t] = true;
+        for (int t = 0; t < fg.n_shell; ++t)
+          {
+            uint32_t idx = fg.shell_idx[s * fg.n_shell + t];
+            uint8_t fl = 0;
+            if (idx != INVALID_DOF)
+              {
+                if (before && (*before)[idx])
+                  fl = BrickTransferGroup::SHELL_OTHER;
+                if (claimed[idx])
+                  idx = INVALID_DOF;
+                else
+                  {
+                    claimed[idx] = true;
+                    fl           = BrickTransferGroup::SHELL_OWN;
+                  }
+              }
+            bg.own_shell.push_back(idx);
+            if (flags)
+              flags[t] = fl;
+          }
+      };
       if (use_bricks && &tf != &tc && pf == pc)
         for (size_t gi = 0; gi < fine.groups.size(); ++gi)
           {
@@ -79,15 +120,19 @@ namespace mgamd
             bg.B          = fg.B;
             bg.Nf         = fg.N;
             bg.Nc         = pc * fg.B / 2 + 1;
+            bg.fused      = (int)gi == fuse_group;
             const int Bc  = fg.B / 2;
+            // pass 1: which slots have a brick patch.  All parents must be hanging-node-free leaves of the coarse mesh;
+            // otherwise (cells not coarsened on this level, or re-refined by the 2:1 balance) the per-cell patches below
+            // take over.  The un-fused bricks of a fused group (halo slots of a sharded level) come first.
+            std::vector<uint32_t>             slots[2]; // [0] un-fused, [1] fused
+            std::vector<std::vector<int32_t>> pars[2];
             for (size_t s = 0; s < fg.n_slots(); ++s)
               {
                 if (fg.fmask[s])
                   continue; // constrained brick: per-cell patches handle its hanging nodes
                 const Cell &fc = tf.cells[fg.first_cell[s]];
                 const Cell  anchor{fc.i & ~(uint32_t)(fg.B - 1), fc.j & ~(uint32_t)(fg.B - 1), fc.k & ~(uint32_t)(fg.B - 1), fc.level};
-                // all parents must be hanging-node-free leaves of the coarse mesh; otherwise (cells not coarsened on
-                // this level, or re-refined by the 2:1 balance) the per-cell patches below take over
                 std::vector<int32_t> parents((size_t)Bc * Bc * Bc, -1);
                 bool                 ok = true;
                 for (int cz = 0; ok && cz < Bc; ++cz)
@@ -102,33 +147,29 @@ namespace mgamd
                       }
                 if (!ok)
                   continue;
-                bg.slot.push_back((uint32_t)s);
+                const int f = (bg.fused && s >= fg.n_halo_slots) ? 1 : 0;
+                slots[f].push_back((uint32_t)s);
                 for (int32_t par : parents)
                   covered[par] = true;
-                for (int Z = 0; Z < bg.Nc; ++Z)
-                  for (int Y = 0; Y < bg.Nc; ++Y)
-                    for (int X = 0; X < bg.Nc; ++X)
-                      {
-                        const int c[3] = {std::min(X / pc, Bc - 1), std::min(Y / pc, Bc - 1), std::min(Z / pc, Bc - 1)};
-                        const int l[3] = {X - c[0] * pc, Y - c[1] * pc, Z - c[2] * pc};
-                        bg.coarse_idx.push_back(coarse.cell_node_index((size_t)parents[(c[2] * Bc + c[1]) * Bc + c[0]], l));
-                      }
-                // interior DoFs are owned by construction; claim the free shell DoFs nobody owns yet
-                for (int t = 0; t < fg.n_interior; ++t)
-                  claimed[fg.interior_base[s] + t] = true;
-                for (int t = 0; t < fg.n_shell; ++t)
-                  {
-                    uint32_t idx = fg.shell_idx[s * fg.n_shell + t];
-                    if (idx != INVALID_DOF)
-                      {
-                        if (claimed[idx])
-                          idx = INVALID_DOF;
-                        else
-                          claimed[idx] = true;
-                      }
-                    bg.own_shell.push_back(idx);
-                  }
+                pars[f].push_back(std::move(parents));
               }
+            bg.n_unfused = slots[0].size();
+            for (int f = 0; f < 2; ++f)
+              for (size_t q = 0; q < slots[f].size(); ++q)
+                {
+                  bg.slot.push_back(slots[f][q]);
+                  for (int Z = 0; Z < bg.Nc; ++Z)
+                    for (int Y = 0; Y < bg.Nc; ++Y)
+                      for (int X = 0; X < bg.Nc; ++X)
+                        {
+                          const int c[3] = {std::min(X / pc, Bc - 1), std::min(Y / pc, Bc - 1), std::min(Z / pc, Bc - 1)};
+                          const int l[3] = {X - c[0] * pc, Y - c[1] * pc, Z - c[2] * pc};
+                          bg.coarse_idx.push_back(coarse.cell_node_index((size_t)pars[f][q][(c[2] * Bc + c[1]) * Bc + c[0]], l));
+                        }
+                }
+            // pass 2: the un-fused bricks claim now; the fused ones after every other patch (below)
+            for (size_t q = 0; q < bg.n_unfused; ++q)
+              claim_brick(bg, fg, bg.slot[q], nullptr, nullptr);
             if (bg.n_bricks())
               bricks.push_back(std::move(bg));
           }
@@ -221,6 +262,21 @@ namespace mgamd
                   g.fine_idx.push_back(idx);
                 }
         }
+      // fused bricks claim last: what is left for them is touched by fused bricks only
+      for (BrickTransferGroup &bg : bricks)
+        if (bg.fused)
+          {
+            const SlotGroup        &fg     = fine.groups[bg.fine_group];
+            const std::vector<bool> before = claimed;
+            bg.shell_flags.assign(bg.n_bricks() * (size_t)fg.n_shell, 0);
+            for (size_t q = bg.n_unfused; q < bg.n_bricks(); ++q)
+              claim_brick(bg, fg, bg.slot[q], &before, &bg.shell_flags[q * (size_t)fg.n_shell]);
+            tail_owned_by_fused.assign(fine.n_tail, 0);
+            for (size_t q = bg.n_unfused; q < bg.n_bricks(); ++q)
+              for (int t = 0; t < fg.n_shell; ++t)
+                if (bg.shell_flags[q * (size_t)fg.n_shell + t] == BrickTransferGroup::SHELL_OWN)
+                  tail_owned_by_fused[bg.own_shell[q * (size_t)fg.n_shell + t] - fine.n_interior] = 1;
+          }
     }
   };
 } // namespace mgamd

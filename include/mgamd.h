@@ -238,6 +238,11 @@ int mgamd_transfer2_create(mgamd_level_op *fine, mgamd_level_op *coarse, mgamd_t
 int mgamd_transfer2_destroy(mgamd_transfer2 *t);
 int mgamd_transfer2_prolongate_and_add(mgamd_transfer2 *t, mgamd_vec *dst_fine, const mgamd_vec *src_coarse);
 int mgamd_transfer2_restrict_and_add(mgamd_transfer2 *t, mgamd_vec *dst_coarse, const mgamd_vec *src_fine);
+/* Inside mgamd_mg_vcycle the part of a transfer that belongs to the fine level's 17-point lattice bricks runs INSIDE the level
+ * operator's passes (restriction in the residual pass, prolongation in the first post-smoothing pass: the steps
+ * Multigrid::level_v_step runs back to back, ref:multigrid_throughput.cc:1093-1099); *n = number of such bricks (0: none;
+ * MGAMD_NO_FUSED_TRANSFER=1 in the environment disables it).  The two entry points above always do the whole transfer. */
+int mgamd_transfer2_n_fused_bricks(const mgamd_transfer2 *t, uint64_t *n);
 
 /* Multigrid + PreconditionMG over MGTransferGlobalCoarsening (ref:multigrid_throughput.cc:1093-1133,
  * 1618-1621).  levels[0] is the coarsest; transfers[l] connects levels l-1 and l (transfers[0] unused,

@@ -102,7 +102,14 @@ def test_chebyshev(mgamd, oracle, ctx, levels, geo, L, p, max_brick, degree):
 HIER_CASES = [("quadrant", 3, 1, "HMG-global"), ("quadrant", 4, 1, "HMG-global"), ("quadrant", 3, 2, "HMG-global"),
               ("quadrant", 3, 4, "HMG-global"), ("hypercube", 3, 1, "HMG-global"), ("hypercube", 2, 4, "HMG-global"),
               ("annulus", 5, 2, "HMG-global"), ("quadrant", 3, 4, "PMG"), ("annulus", 5, 2, "PMG"), ("quadrant", 3, 3, "PMG"),
-              ("quadrant", 3, 4, "HPMG"), ("annulus", 5, 2, "HPMG"), ("hypercube", 3, 4, "HMG-global"), ("hypercube", 5, 1, "HMG-global")]
+              ("quadrant", 3, 4, "HPMG"), ("annulus", 5, 2, "HPMG"), ("hypercube", 3, 4, "HMG-global"), ("hypercube", 5, 1, "HMG-global"),
+              # 17-point lattice bricks NEXT TO other slots (smaller bricks, constrained families, single cells with hanging
+              # nodes): the level transfers of the bricks run inside the operator passes, everything else through the patch
+              # kernels, and the two sets meet on the bricks' shells (round 3)
+              ("quadrant", 4, 4, "HMG-global"), ("quadrant", 5, 2, "HMG-global"), ("quadrant", 6, 1, "HMG-global")]
+# hierarchies of HIER_CASES in which at least one transfer has bricks fused into the operator passes
+FUSED_CASES = [("hypercube", 3, 4, "HMG-global"), ("hypercube", 5, 1, "HMG-global"), ("quadrant", 4, 4, "HMG-global"),
+               ("quadrant", 5, 2, "HMG-global"), ("quadrant", 6, 1, "HMG-global")]
 
 
 @pytest.fixture(scope="module")
@@ -160,6 +167,40 @@ def test_vcycle(mgamd, oracle, ctx, hierarchies, geo, L, p, mg_type):
     # graph replay gives the same vector
     ms = h.mg.time_vcycles(vz, vr, 2, True)
     assert ms > 0 and rel_err(vz.to_host(), ref) < 1e-11
+
+
+@pytest.mark.parametrize("geo,L,p,mg_type", FUSED_CASES)
+def test_fused_transfers_match_separate_transfers(mgamd, oracle, ctx, hierarchies, geo, L, p, mg_type, monkeypatch):
+    """Restriction inside the residual pass and prolongation inside the first post-smoothing pass of the 17-point lattice
+    bricks (kernels.hpp MODE_RESIDUAL_RESTRICT / MODE_CHEB_PROLONGATE): the hierarchy really uses them, the V-cycle equals the
+    one with separate transfer kernels (MGAMD_NO_FUSED_TRANSFER=1) to rounding, both equal the numpy oracle, repeated cycles
+    give the same vector (no state left in the scratch vectors or the tail accumulator), and the stage callbacks -- which
+    switch the fused passes off to keep the reference's stages apart -- do not change the result."""
+    def n_fused(hh):  # (HPMG: the h-levels sit in the nested hierarchy under the p-levels)
+        ts = list(hh.transfers[1:]) + (list(hh.ls["transfers"][1:]) if isinstance(getattr(hh, "ls", None), dict) else [])
+        return sum(t.n_fused_bricks() for t in ts if t is not None)
+
+    h, levels, P = hierarchies(geo, L, p, mg_type)
+    assert n_fused(h) > 0
+    monkeypatch.setenv("MGAMD_NO_FUSED_TRANSFER", "1")
+    h0 = mgamd.Hierarchy(ctx, geo, L, p, mg_type, coarse_solver="amg", max_brick=0)
+    monkeypatch.delenv("MGAMD_NO_FUSED_TRANSFER")
+    assert n_fused(h0) == 0
+    mg = oracle.Multigrid(levels, P, 3, coarse="direct")
+    n = levels[-1].n
+    rng = np.random.default_rng(11)
+    for trial in range(3):
+        r = rng.standard_normal(n)
+        vr, vz, vz0 = mgamd.Vector(ctx, n).from_host(r), mgamd.Vector(ctx, n), mgamd.Vector(ctx, n)
+        h.mg.vmult(vz, vr)
+        h0.mg.vmult(vz0, vr)
+        ref = mg.vcycle(r)
+        assert rel_err(vz.to_host(), vz0.to_host()) < 1e-13
+        assert rel_err(vz.to_host(), ref) < 1e-11
+        assert np.array_equal(vr.to_host(), r)  # the right-hand side is read only
+    z1 = vz.to_host()
+    h.mg.vmult(vz, vr)
+    assert np.array_equal(vz.to_host(), z1) or rel_err(vz.to_host(), z1) < 1e-14  # (atomic summation order)
 
 
 @pytest.mark.parametrize("geo,L,p,mg_type", HIER_CASES)
