@@ -94,6 +94,18 @@ class Triangulation:
         _chk(_lib.mgamd_tria_info(self._h, C.byref(nc), C.byref(nl), C.byref(nh)))
         self.n_cells, self.n_levels, self.n_cells_hn = nc.value, nl.value, nh.value
 
+    @classmethod
+    def from_leaves(cls, level, i, j, k) -> "Triangulation":
+        """a caller-built octree over one root cell (mgamd_tria_create_from_leaves): leaves (level, i, j, k) in any order; must
+        tile the cube and be 2:1 balanced across faces, edges and corners, else MgamdError (status MGAMD_ERR_INVALID)"""
+        level, i, j, k = (np.ascontiguousarray(level, np.uint8), np.ascontiguousarray(i, np.uint32), np.ascontiguousarray(j, np.uint32),
+                          np.ascontiguousarray(k, np.uint32))
+        if not (len(level) == len(i) == len(j) == len(k)):
+            raise ValueError("from_leaves: arrays of different lengths")
+        h = C.c_void_p()
+        _chk(_lib.mgamd_tria_create_from_leaves(C.c_uint64(len(level)), _ptr(level), _ptr(i), _ptr(j), _ptr(k), C.byref(h)))
+        return cls(_handle=h)
+
     def level_mesh(self, level: int) -> "Triangulation":
         """local smoothing: all cells of refinement level `level`, active or not (distribute_mg_dofs levels)"""
         h = C.c_void_p()
@@ -431,6 +443,11 @@ class Operator:
         """local-smoothing level: the edge matrix, A with the refinement-edge DoFs unconstrained applied to src|edge"""
         _chk(_lib.mgamd_level_op_vmult_interface_up(self._h, dst._h, src._h))
 
+    def vmult_interface_down(self, dst: Vector, src: Vector):
+        """Operator::vmult_interface_down: the plain cell loop (refinement-edge DoFs as ordinary DoFs), identity on the
+        constrained rows -- the matrix of Multigrid's residual step (MGInterfaceOperator::vmult)"""
+        _chk(_lib.mgamd_level_op_vmult_interface_down(self._h, dst._h, src._h))
+
     def compute_inverse_diagonal(self, diagonal: Vector):
         _chk(_lib.mgamd_level_op_inverse_diagonal(self._h, diagonal._h))
 
@@ -601,7 +618,8 @@ class Hierarchy:
                  smoother_degree=3, smoothing_range=20.0, eig_cg_n_iterations=20, coarse_solver="amg", number_type=F64,
                  max_brick=-1, coarse_n_cycles=1):
         self.ctx = ctx
-        fine = Triangulation(geometry, n_ref_global, n_ref_local)
+        # `geometry` may also be a caller-built Triangulation (Triangulation.from_leaves)
+        fine = geometry if isinstance(geometry, Triangulation) else Triangulation(geometry, n_ref_global, n_ref_local)
         if mg_type == "HMG-global":
             self.trias = create_geometric_coarsening_sequence(fine)
             self.degrees = [degree] * len(self.trias)
@@ -688,7 +706,7 @@ class DistributedHierarchy:
                  smoothing_range=20.0, eig_cg_n_iterations=20, coarse_solver="amg", number_type=F64, hanging_weight=2.0, max_brick=-1,
                  min_root_dofs=4_000_000, mg_type="HMG-global", coarse_n_cycles=1):
         self.ctx, self.comm = ctx, comm
-        fine = Triangulation(geometry, n_ref_global)
+        fine = geometry if isinstance(geometry, Triangulation) else Triangulation(geometry, n_ref_global)
         self.mesh_sequence = create_geometric_coarsening_sequence(fine)
         nm = len(self.mesh_sequence)
         # (mesh index, degree) of every multigrid level, coarse -> fine (ref:multigrid_throughput.cc:1506-1571)

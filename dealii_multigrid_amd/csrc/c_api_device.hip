@@ -610,6 +610,15 @@ mgamd_level_op_vmult_interface_up(mgamd_level_op *op, mgamd_vec *dst, const mgam
 }
 
 int
+mgamd_level_op_vmult_interface_down(mgamd_level_op *op, mgamd_vec *dst, const mgamd_vec *src)
+{
+  MGAMD_TRY
+  REQUIRE(op && dst && src);
+  op->op->vmult_interface_down(*dst, *src);
+  MGAMD_CATCH
+}
+
+int
 mgamd_mg_set_collapse(mgamd_mg *mg, int enable, unsigned *collapse_level)
 {
   MGAMD_TRY

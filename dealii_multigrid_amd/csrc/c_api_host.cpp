@@ -35,6 +35,29 @@ mgamd_tria_create(const char *geometry, unsigned n_ref_global, unsigned n_ref_lo
 }
 
 int
+mgamd_tria_create_from_leaves(uint64_t n_leaves, const uint8_t *level, const uint32_t *i, const uint32_t *j, const uint32_t *k, mgamd_tria **out)
+{
+  MGAMD_TRY
+  if (!level || !i || !j || !k || !out)
+    throw std::invalid_argument("null argument");
+  std::vector<Cell> leaves(n_leaves);
+  for (uint64_t t = 0; t < n_leaves; ++t)
+    leaves[t] = Cell{i[t], j[t], k[t], level[t]};
+  auto *t = new mgamd_tria;
+  try
+    {
+      t->tria = std::make_shared<Tria>(Tria::from_leaves_checked(std::move(leaves)));
+    }
+  catch (...)
+    {
+      delete t;
+      throw;
+    }
+  *out = t;
+  MGAMD_CATCH
+}
+
+int
 mgamd_tria_coarsen(const mgamd_tria *fine, mgamd_tria **out)
 {
   MGAMD_TRY

@@ -901,16 +901,78 @@ namespace mgamd
           out[c * P + b] += T(E[a * (P + 1) + b]) * in[c * 2 * P + a];
   }
 
+  // The same with HALF of the matrix: the GLL nodes are symmetric, so E[2P - a][P - b] = E[a][b], and the rows of fine nodes that
+  // coincide with a coarse node (a = 0; a = P for even P) are unit vectors.  Eh = rows 0..P of E; only the entries of the
+  // non-trivial rows are ever read (15 doubles at p = 4 instead of 45: the fused kernels keep them in scalar registers next to
+  // the operator's matrices -- with the full matrix the compiler spilled scalars into vector lanes and vectors to scratch,
+  // whose reloads wait for EVERY outstanding memory operation of the wave).
+  template <int P>
+  __device__ __forceinline__ constexpr bool
+  embed_row_is_unit(int a) // a in 0..P
+  {
+    return a == 0 || (P % 2 == 0 && a == P);
+  }
+  template <typename T, int P, int BC>
+  __device__ __forceinline__ void
+  line_embed_sym(const double *__restrict__ Eh, const T (&in)[P * BC + 1], T (&out)[2 * P * BC + 1])
+  {
+#pragma unroll
+    for (int c = 0; c < BC; ++c)
+#pragma unroll
+      for (int a = (c == 0 ? 0 : 1); a <= 2 * P; ++a)
+        {
+          const int  ar  = a <= P ? a : 2 * P - a; // row of Eh
+          const bool mir = a > P;                  // mirrored columns
+          T          s;
+          if (embed_row_is_unit<P>(ar))
+            s = in[c * P + (ar == 0 ? (mir ? P : 0) : P / 2)];
+          else
+            {
+              s = T(0);
+#pragma unroll
+              for (int b = 0; b <= P; ++b)
+                s += T(Eh[ar * (P + 1) + b]) * in[c * P + (mir ? P - b : b)];
+            }
+          out[c * 2 * P + a] = s;
+        }
+  }
+  template <typename T, int P, int BC>
+  __device__ __forceinline__ void
+  line_embed_sym_T(const double *__restrict__ Eh, const T (&in)[2 * P * BC + 1], T (&out)[P * BC + 1])
+  {
+#pragma unroll
+    for (int i = 0; i < P * BC + 1; ++i)
+      out[i] = T(0);
+#pragma unroll
+    for (int c = 0; c < BC; ++c)
+#pragma unroll
+      for (int a = (c == 0 ? 0 : 1); a <= 2 * P; ++a) // a fine node shared by two coarse cells counts once
+        {
+          const int  ar  = a <= P ? a : 2 * P - a;
+          const bool mir = a > P;
+          const T    v   = in[c * 2 * P + a];
+          if (embed_row_is_unit<P>(ar))
+            out[c * P + (ar == 0 ? (mir ? P : 0) : P / 2)] += v;
+          else
+            {
+#pragma unroll
+              for (int b = 0; b <= P; ++b)
+                out[c * P + (mir ? P - b : b)] += T(Eh[ar * (P + 1) + b]) * v;
+            }
+        }
+  }
+
   // Tables of the transfers fused into the operator (Transfer2 in runtime.hip builds them, indexed by SLOT of the fused group):
   //   flags[slot * 256 + tid]  bit 15: the slot is fused; bits 2 it, 2 it + 1: BrickTransferGroup::SHELL_OWN / SHELL_OTHER of
-  //                            shell entry tid + 256 it of that slot
+  //                            shell entry tid + 256 it of that slot; bit 16 + it: coarse lattice node tid + 256 it is a
+  //                            Dirichlet DoF (its coarse_idx entry is DEV_INVALID)
   //   coarse_idx[slot * NC^3 + c]  coarse DoF of coarse lattice node c (x fastest), DEV_INVALID = Dirichlet or slot not fused
   template <typename T, int P>
   struct FusedTransferDev
   {
-    const uint16_t *flags      = nullptr;
+    const uint32_t *flags      = nullptr;
     const uint32_t *coarse_idx = nullptr;
-    double          E[(2 * P + 1) * (P + 1)];
+    double          Eh[(P + 1) * (P + 1)]; // rows 0..P of the 1D h-embedding (line_embed_sym)
     T              *coarse  = nullptr; // RESTRICT: the coarse defect (+=);  PROLONGATE: the coarse solution (read only)
     T              *x_inout = nullptr; // PROLONGATE: == src; x + P x_c of the fused bricks' interior DoFs is stored in place
     T              *scratch = nullptr; // PROLONGATE: x + P x_c of the shell DoFs a fused brick owns (indexed like x)
@@ -1452,6 +1514,8 @@ namespace mgamd
           if (FUSE_R)
             sbv[it] = args.epi.b[((fl >> (2 * it)) & 1u) ? gi : 0];
         }
+      // (the coarse values last: measured 3.80 vs 3.91 ms per octant p=4 post-smoothing against loading them first, which lets
+      // the embedding start while x is still in flight but delays x behind 3 more loads)
       if constexpr (FUSE_P)
         {
 #pragma unroll
@@ -1503,18 +1567,14 @@ namespace mgamd
         if constexpr (FUSE_P)
           if (fused_slot)
             {
-              // the coarse lattice at coordinates < NC of the scratch lattice, embedded in place z, y, x (a thread reads its line
-              // into registers before it writes it back; lines of one sweep are disjoint)
+              // the coarse values, COMPACT (NC^3, x fastest) in the first lattice, which is free until this slot's values go
+              // there: linear addresses (positions computed from the thread index were hoisted out of the loop and spilled).
+              // z sweep from there into the scratch lattice, then y and x in place (a thread reads its line into registers
+              // before it writes it back; lines of one sweep are disjoint)
 #pragma unroll
               for (int it = 0; it < ITC; ++it)
-                {
-                  const int idx = tid + it * BLOCK;
-                  if (idx < NC3)
-                    {
-                      const int x = idx % NC, y = (idx / NC) % NC, z = idx / (NC * NC);
-                      bufB[(z * G::N + y) * G::N + x] = cgi[it] != DEV_INVALID ? cval[it] : T(0);
-                    }
-                }
+                if (tid + it * BLOCK < NC3)
+                  bufA[tid + it * BLOCK] = ((flcur >> (16 + it)) & 1u) ? T(0) : cval[it]; // (the flag, not the index: 3 registers)
               __syncthreads();
               T cin[NC], cout[G::N];
               for (int l = tid; l < NC * NC; l += BLOCK)
@@ -1522,8 +1582,8 @@ namespace mgamd
                   const int b0 = (l / NC) * G::N + l % NC;
 #pragma unroll
                   for (int i = 0; i < NC; ++i)
-                    cin[i] = bufB[b0 + i * G::N * G::N];
-                  line_embed<T, P, BC>(args.fused.E, cin, cout);
+                    cin[i] = bufA[l + i * NC * NC];
+                  line_embed_sym<T, P, BC>(args.fused.Eh, cin, cout);
 #pragma unroll
                   for (int i = 0; i < G::N; ++i)
                     bufB[b0 + i * G::N * G::N] = cout[i];
@@ -1535,7 +1595,7 @@ namespace mgamd
 #pragma unroll
                   for (int i = 0; i < NC; ++i)
                     cin[i] = bufB[b0 + i * G::N];
-                  line_embed<T, P, BC>(args.fused.E, cin, cout);
+                  line_embed_sym<T, P, BC>(args.fused.Eh, cin, cout);
 #pragma unroll
                   for (int i = 0; i < G::N; ++i)
                     bufB[b0 + i * G::N] = cout[i];
@@ -1547,7 +1607,7 @@ namespace mgamd
 #pragma unroll
                   for (int i = 0; i < NC; ++i)
                     cin[i] = bufB[b0 + i];
-                  line_embed<T, P, BC>(args.fused.E, cin, cout);
+                  line_embed_sym<T, P, BC>(args.fused.Eh, cin, cout);
 #pragma unroll
                   for (int i = 0; i < G::N; ++i)
                     bufB[b0 + i] = cout[i];
@@ -1638,7 +1698,7 @@ namespace mgamd
 #pragma unroll
                     for (int i = 0; i < G::N; ++i)
                       rin[i] = bufA[b0 + i];
-                    line_embed_T<T, P, BC>(args.fused.E, rin, rout);
+                    line_embed_sym_T<T, P, BC>(args.fused.Eh, rin, rout);
 #pragma unroll
                     for (int i = 0; i < NC; ++i)
                       bufA[b0 + i] = rout[i];
@@ -1650,34 +1710,29 @@ namespace mgamd
 #pragma unroll
                     for (int i = 0; i < G::N; ++i)
                       rin[i] = bufA[b0 + i * G::N];
-                    line_embed_T<T, P, BC>(args.fused.E, rin, rout);
+                    line_embed_sym_T<T, P, BC>(args.fused.Eh, rin, rout);
 #pragma unroll
                     for (int i = 0; i < NC; ++i)
                       bufA[b0 + i * G::N] = rout[i];
                   }
                 __syncthreads();
+                // (the last sweep leaves the coarse lattice COMPACT in the scratch lattice: linear addresses for the scatter)
                 for (int l = tid; l < NC * NC; l += BLOCK)
                   {
                     const int b0 = (l / NC) * G::N + l % NC;
 #pragma unroll
                     for (int i = 0; i < G::N; ++i)
                       rin[i] = bufA[b0 + i * G::N * G::N];
-                    line_embed_T<T, P, BC>(args.fused.E, rin, rout);
+                    line_embed_sym_T<T, P, BC>(args.fused.Eh, rin, rout);
 #pragma unroll
                     for (int i = 0; i < NC; ++i)
-                      bufA[b0 + i * G::N * G::N] = rout[i];
+                      bufB[l + i * NC * NC] = rout[i];
                   }
                 __syncthreads();
 #pragma unroll
                 for (int it = 0; it < ITC; ++it)
-                  {
-                    const int idx = tid + it * BLOCK;
-                    if (idx < NC3 && cgi[it] != DEV_INVALID)
-                      {
-                        const int x = idx % NC, y = (idx / NC) % NC, z = idx / (NC * NC);
-                        atomic_add(&args.fused.coarse[cgi[it]], bufA[(z * G::N + y) * G::N + x]);
-                      }
-                  }
+                  if (tid + it * BLOCK < NC3 && cgi[it] != DEV_INVALID)
+                    atomic_add(&args.fused.coarse[cgi[it]], bufB[tid + it * BLOCK]);
               }
           }
         else

@@ -251,7 +251,7 @@ namespace mgamd
   struct FusedTransferHost
   {
     int                 group = -1;
-    const uint16_t     *flags = nullptr;      // [n_slots of the group][256]
+    const uint32_t     *flags = nullptr;      // [n_slots of the group][256]
     const uint32_t     *coarse_idx = nullptr; // [n_slots of the group][nc3]
     uint32_t            nc3 = 0;
     std::vector<double> E;                    // 1D h-embedding (2p+1) x (p+1)
@@ -545,8 +545,12 @@ namespace mgamd
             throw std::runtime_error("fused transfer: tables do not match the brick kernel");
           a.fused.flags      = f.flags + begin * G::ABLOCK;
           a.fused.coarse_idx = f.coarse_idx + begin * NC3;
-          for (size_t i = 0; i < f.E.size(); ++i)
-            a.fused.E[i] = f.E[i];
+          for (int i = 0; i < (P + 1) * (P + 1); ++i) // rows 0..P; the kernel uses E[2P - a][P - b] = E[a][b] for the rest
+            a.fused.Eh[i] = f.E[i];
+          for (int ar = 0; ar <= P; ++ar)
+            for (int b = 0; b <= P; ++b)
+              if (std::fabs(f.E[(2 * P - ar) * (P + 1) + (P - b)] - f.E[ar * (P + 1) + b]) > 1e-14)
+                throw std::runtime_error("fused transfer: the 1D embedding is not centro-symmetric");
           a.fused.coarse  = f.coarse;
           a.fused.x_inout = f.x_inout;
           a.fused.scratch = f.scratch;
@@ -707,21 +711,25 @@ namespace mgamd
       Epilogue<T> e{dst, src, nullptr, nullptr, nullptr, T(0), T(0), T(0)};
       apply<MODE_VMULT>(src, e);
     }
+    // t = b - A x, the residual step of Multigrid::level_v_step.  The reference hands Multigrid an mg::Matrix built from
+    // MatrixFreeOperators::MGInterfaceOperator<LevelMatrixType> (ref:multigrid_throughput.cc:857-862), whose vmult calls
+    // Operator::vmult_interface_down (ref:include/operator.h:191-201): the plain cell loop, identity on the constrained
+    // (Dirichlet) rows only -- on a local-smoothing level the refinement-edge DoFs are ordinary DoFs there, rows and columns
+    // (EDGE_IN).  After the zero-start pre-smoother x vanishes on them, so the edge rows are t_E = b_E - A_{E,I} x_I.
     void
-    residual_raw(T *t, const T *b, const T *x) // t = b - A x
+    residual_raw(T *t, const T *b, const T *x)
     {
       Epilogue<T> e{t, x, nullptr, b, nullptr, T(0), T(0), T(0)};
-      if (tables->n_edge == 0)
-        {
-          apply<MODE_RESIDUAL>(x, e);
-          return;
-        }
-      // local-smoothing level: the rows of the refinement-edge DoFs belong to the residual that is restricted,
-      // t_E = b_E - x_E - A_{E,I} x_I (identity row + coupling to the interior of the refined region)
-      apply<MODE_RESIDUAL>(x, e, false, 0, EDGE_ROWS);
-      const size_t first_edge = (size_t)tables->n_interior + tables->n_tail;
-      hipLaunchKernelGGL(vec_sadd_kernel<T>, grid_for(tables->n_edge), 256, 0, ctx->stream, t + first_edge, T(1), T(-1), x + first_edge,
-                         (size_t)tables->n_edge);
+      apply<MODE_RESIDUAL>(x, e, false, 0, tables->n_edge ? EDGE_IN : EDGE_OUT);
+    }
+    // Operator::vmult_interface_down (ref:include/operator.h:191-201)
+    void
+    vmult_interface_down(mgamd_vec &dst, const mgamd_vec &src) override
+    {
+      if (dst.n != n_dofs() || src.n != n_dofs() || dst.data == src.data)
+        throw std::invalid_argument("vmult_interface_down: bad vectors");
+      Epilogue<T> e{dst.as<T>(), src.as<T>(), nullptr, nullptr, nullptr, T(0), T(0), T(0)};
+      apply<MODE_VMULT>(src.as<T>(), e, false, 0, tables->n_edge ? EDGE_IN : EDGE_OUT);
     }
     // dst = A^{edge DoFs unconstrained} (src restricted to the refinement-edge DoFs); tmp: scratch of n_dofs entries
     // (Operator::vmult_interface_up, ref:include/operator.h:203-226)

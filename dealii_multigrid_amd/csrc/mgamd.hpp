@@ -311,6 +311,17 @@ namespace mgamd
     {
       vmult(dst, src); // ref:include/operator.h:185-189
     }
+    // ref:include/operator.h:191-201 and :203-226 (what MatrixFreeOperators::MGInterfaceOperator::vmult / Tvmult forward to)
+    void
+    vmult_interface_down(Vector &dst, const Vector &src) const
+    {
+      check(mgamd_level_op_vmult_interface_down(h.get(), dst.get(), src.get()));
+    }
+    void
+    vmult_interface_up(Vector &dst, const Vector &src) const
+    {
+      check(mgamd_level_op_vmult_interface_up(h.get(), dst.get(), src.get()));
+    }
     void
     compute_inverse_diagonal(Vector &diagonal) const
     {

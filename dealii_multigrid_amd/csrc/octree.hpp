@@ -184,6 +184,11 @@ namespace mgamd
     create(const std::string &geometry, unsigned n_ref_global, unsigned n_ref_local);
     static Tria
     from_cells(std::vector<Cell> leaves); // must be a balanced partition of the cube
+    // a caller-built octree (e.g. the active cells of a parallel::distributed::Triangulation over one root cell): checks that
+    // the leaves tile the cube exactly and are 2:1 balanced across faces, edges and corners (p4est's full balance, which
+    // deal.II requests); throws std::invalid_argument otherwise
+    static Tria
+    from_leaves_checked(std::vector<Cell> leaves);
     Tria
     coarsen_global() const; // one level of the geometric coarsening sequence
     // local smoothing: ALL cells of refinement level `level`, active or not (DoFHandler::distribute_mg_dofs levels)
@@ -420,6 +425,44 @@ namespace mgamd
     Tria t;
     t.cells = std::move(leaves);
     t.finalize();
+    return t;
+  }
+
+  inline Tria
+  Tria::from_leaves_checked(std::vector<Cell> leaves)
+  {
+    if (leaves.empty())
+      throw std::invalid_argument("octree: no leaves");
+    for (const Cell &c : leaves)
+      if (c.level > LMAX - 1 || ((uint64_t)c.i >> c.level) || ((uint64_t)c.j >> c.level) || ((uint64_t)c.k >> c.level))
+        throw std::invalid_argument("octree: leaf (level " + std::to_string(c.level) + ", " + std::to_string(c.i) + ", " + std::to_string(c.j) +
+                                    ", " + std::to_string(c.k) + ") outside the level's index range or deeper than " + std::to_string(LMAX - 1));
+    Tria t = from_cells(std::move(leaves));
+    // exact tiling: in Morton order leaf t covers [morton, morton + 8^(LMAX - level))
+    uint64_t next = 0;
+    for (const Cell &c : t.cells)
+      {
+        if (morton(c) != next)
+          throw std::invalid_argument(morton(c) < next ? "octree: leaves overlap (a cell and one of its descendants, or a duplicate)" :
+                                                         "octree: the leaves do not cover the cube (gap in the Morton order)");
+        next += (uint64_t)1 << (3 * (LMAX - c.level));
+      }
+    if (next != ((uint64_t)1 << (3 * LMAX)))
+      throw std::invalid_argument("octree: the leaves do not cover the cube");
+    // 2:1 balance over all 26 neighbour directions: the leaf that covers a same-level neighbour region may be at most one
+    // level coarser (a finer neighbourhood is checked from the finer side)
+    for (const Cell &c : t.cells)
+      for (int dz = -1; dz <= 1; ++dz)
+        for (int dy = -1; dy <= 1; ++dy)
+          for (int dx = -1; dx <= 1; ++dx)
+            {
+              if (!dx && !dy && !dz)
+                continue;
+              const int nb = t.find_leaf(c.level, (int64_t)c.i + dx, (int64_t)c.j + dy, (int64_t)c.k + dz);
+              if (nb >= 0 && (int)t.cells[nb].level < (int)c.level - 1)
+                throw std::invalid_argument("octree: not 2:1 balanced across faces, edges and corners at leaf (level " + std::to_string(c.level) +
+                                            ", " + std::to_string(c.i) + ", " + std::to_string(c.j) + ", " + std::to_string(c.k) + ")");
+            }
     return t;
   }
 

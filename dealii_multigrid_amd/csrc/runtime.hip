@@ -624,7 +624,7 @@ namespace mgamd
     // Transfers fused into the fine level's operator passes (kernels.hpp MODE_RESIDUAL_RESTRICT / MODE_CHEB_PROLONGATE): tables by
     // SLOT of the fused group.  MGAMD_NO_FUSED_TRANSFER=1 disables them (development A/B; same results up to rounding).
     FusedTransferHost<T> fused;
-    DBuf<uint16_t>       fused_flags;
+    DBuf<uint32_t>       fused_flags;
     DBuf<uint32_t>       fused_coarse_idx;
     DBuf<uint8_t>        fused_tail_flags;
     size_t               n_fused_bricks = 0;
@@ -689,7 +689,7 @@ namespace mgamd
               const size_t     ns  = fg.n_slots(), nsh = (size_t)fg.n_shell, nc3 = (size_t)bg.Nc * bg.Nc * bg.Nc;
               if (2 * ((nsh + 255) / 256) > 15)
                 throw std::runtime_error("fused transfer: shell too large for the flag word");
-              std::vector<uint16_t> fl(ns * 256, 0);
+              std::vector<uint32_t> fl(ns * 256, 0);
               std::vector<uint32_t> ci(ns * nc3, INVALID_DOF);
               for (size_t q = bg.n_unfused; q < bg.n_bricks(); ++q)
                 {
@@ -697,8 +697,11 @@ namespace mgamd
                   for (size_t t = 0; t < 256; ++t)
                     fl[sl * 256 + t] = 0x8000u;
                   for (size_t t = 0; t < nsh; ++t)
-                    fl[sl * 256 + t % 256] |= (uint16_t)((bg.shell_flags[q * nsh + t] & 3u) << (2 * (t / 256)));
+                    fl[sl * 256 + t % 256] |= (uint32_t)(bg.shell_flags[q * nsh + t] & 3u) << (2 * (t / 256));
                   std::copy(bg.coarse_idx.begin() + q * nc3, bg.coarse_idx.begin() + (q + 1) * nc3, ci.begin() + sl * nc3);
+                  for (size_t t = 0; t < nc3; ++t)
+                    if (bg.coarse_idx[q * nc3 + t] == INVALID_DOF)
+                      fl[sl * 256 + t % 256] |= 1u << (16 + t / 256);
                 }
               fused_flags.upload(fl);
               fused_coarse_idx.upload(ci);

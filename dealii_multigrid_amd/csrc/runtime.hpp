@@ -195,6 +195,8 @@ namespace mgamd
     compute_inverse_diagonal(mgamd_vec &d) = 0;
     virtual void
     vmult_interface_up(mgamd_vec &dst, const mgamd_vec &src) = 0; // local-smoothing levels: the edge matrix
+    virtual void
+    vmult_interface_down(mgamd_vec &dst, const mgamd_vec &src) = 0; // the level matrix of Multigrid's residual step
     virtual size_t
     read_debug_stamps(unsigned long long *out, size_t max_count) = 0;
     void

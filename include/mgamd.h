@@ -55,6 +55,13 @@ const char *mgamd_version(void);
  * create_annulus, create_circle}: ref:multigrid_throughput.cc:2048-2062, ref:include/grid_generator.h.
  * geometry in {"hypercube","quadrant","quadrant_flexible","annulus","circle"}. */
 int mgamd_tria_create(const char *geometry, unsigned n_ref_global, unsigned n_ref_local, mgamd_tria **out);
+/* A caller-built mesh: the active cells of a parallel::distributed::Triangulation<3> over ONE root cell [-1,1]^3 (what the
+ * reference hands to the path: ref:multigrid_throughput.cc:2048-2062 builds it, :1540-1604 consumes it), given as octree leaves
+ * (level, i, j, k), 0 <= i, j, k < 2^level, in any order.  The leaves must tile the cube exactly and be 2:1 balanced across
+ * faces, edges and corners (p4est's full balance, deal.II's default); otherwise MGAMD_ERR_INVALID with the offending leaf in
+ * mgamd_last_error().  Zero Dirichlet data on the whole boundary, as for the named geometries. */
+int mgamd_tria_create_from_leaves(uint64_t n_leaves, const uint8_t *level, const uint32_t *i, const uint32_t *j, const uint32_t *k,
+                                  mgamd_tria **out);
 /* one level of MGTransferGlobalCoarseningTools::create_geometric_coarsening_sequence
  * (ref:multigrid_throughput.cc:2219-2224): coarsen every family once, re-balance. */
 int mgamd_tria_coarsen(const mgamd_tria *fine, mgamd_tria **out);
@@ -273,6 +280,11 @@ int mgamd_mg_create_local_smoothing(mgamd_ctx *ctx, unsigned n_levels, mgamd_lev
 /* Operator::vmult_interface_up (ref:include/operator.h:203-226): dst = A with the refinement-edge DoFs unconstrained, applied
  * to src restricted to those DoFs (MatrixFreeOperators::MGInterfaceOperator::Tvmult) */
 int mgamd_level_op_vmult_interface_up(mgamd_level_op *op, mgamd_vec *dst, const mgamd_vec *src);
+/* Operator::vmult_interface_down (ref:include/operator.h:191-201): the plain cell loop, identity on the constrained (Dirichlet,
+ * hanging) rows only; on a local-smoothing level the refinement-edge DoFs take part as ordinary DoFs.  This is what
+ * MatrixFreeOperators::MGInterfaceOperator::vmult forwards to, i.e. the matrix of Multigrid's residual step in the reference
+ * (ref:multigrid_throughput.cc:857-862).  On a level without refinement edges it equals mgamd_level_op_vmult. */
+int mgamd_level_op_vmult_interface_down(mgamd_level_op *op, mgamd_vec *dst, const mgamd_vec *src);
 /* Levels up to 2048 DoFs (MGAMD_COLLAPSE_MAX_DOFS) with a direct coarse solver are applied as ONE tabulated dense matrix
  * (the zero-start V-cycle below a level is a linear map of its defect; result-equivalent).  This switches the
  * tabulated path off/on at run time (bench.py reports the cycle time both ways); *collapse_level = the level it replaces

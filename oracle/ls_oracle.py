@@ -13,15 +13,16 @@ deal.II pieces restated:
   * edge matrices (Janssen & Kanschat 2011; deal.II Multigrid::level_v_step): the level operator only couples the
     interior of the refined region; the coupling across the refinement edge enters twice,
       up:   after the coarse-grid correction  defect_l -= A_l^{no edge constraints} (x_l restricted to the edge DoFs)
-            (Multigrid::set_edge_in_matrix + operator.h:203-226 vmult_interface_up), and
-      down: the residual that is restricted carries the rows of the edge DoFs, t_E = d_E - x_E - A_{E,I} x_I
-            (deal.II: edge_out / vmult_interface_down of MatrixFreeOperators::Base).
-    UNCERTAINTY (recorded in DESIGN.md): the reference calls set_edge_in_matrix only and its Operator::vmult returns
-    identity rows on the edge DoFs (operator.h:152-183); read literally the `down` part would be dropped.  That literal
-    variant is a NON-symmetric preconditioner: in this oracle CG then stalls (octant L=4 p=1: residual reduced by 0.03
-    after 60 iterations; relative asymmetry of the V-cycle 0.18), whereas with the `down` part the V-cycle is symmetric to
-    rounding and CG needs 4-5 iterations like global coarsening, which is what the reference's publications report for
-    local smoothing.  The oracle (and the product) implement the symmetric algorithm.
+            (Multigrid::set_edge_in_matrix, ref:multigrid_throughput.cc:1105,1130, + operator.h:203-226
+            vmult_interface_up), and
+      down: the matrix of the RESIDUAL step is not Operator::vmult: the reference builds Multigrid's mg::Matrix from
+            MatrixFreeOperators::MGInterfaceOperator<LevelMatrixType> (ref:multigrid_throughput.cc:857-862), whose vmult
+            forwards to Operator::vmult_interface_down (ref:include/operator.h:191-201) -- the plain cell loop with identity
+            on the Dirichlet rows only, the refinement-edge DoFs being ordinary rows AND columns (`A_down` below).  Hence the
+            residual that is restricted carries the edge rows, t = d - A_down x.  The zero-start pre-smoother (level operator
+            with identity edge rows, zero defect on the edge DoFs) leaves x_E = 0, so t_E = d_E - A_{E,I} x_I.
+    (Rounds 1-2 recorded this as an ambiguity because Operator::vmult has identity edge rows; lines 857-862 settle it.  The
+    variant WITHOUT the edge rows is a non-symmetric preconditioner under which CG stalls in this oracle.)
   * MGTransferMatrixFree: P_l per refined cell of level l-1, weights 1/multiplicity, boundary DoFs zero
   * copy_to_mg / copy_from_mg (MGLevelGlobalTransfer, skip_interface_dofs): a DoF of the active mesh lives on the level of
     its active cell unless it sits on that level's refinement edge
@@ -70,7 +71,9 @@ class LSLevel:
         free = sp.diags((~self.constrained).astype(float))
         self.A = (free @ K @ free + sp.diags(self.constrained.astype(float))).tocsr()
         self.A_edge_in = (sp.diags((~lv.dirichlet).astype(float)) @ K @ sp.diags(edge.astype(float))).tocsr()
-        self.A_edge_out = (sp.diags(edge.astype(float)) @ K @ free).tocsr()  # rows of the edge DoFs, interior columns
+        # Operator::vmult_interface_down (ref:include/operator.h:191-201): only the Dirichlet DoFs are constrained
+        nd = sp.diags((~lv.dirichlet).astype(float))
+        self.A_down = (nd @ K @ nd + sp.diags(lv.dirichlet.astype(float))).tocsr()
         d = self.A.diagonal()
         self.inv_diag = np.where(np.abs(d) > 1e-10, 1.0 / d, 1.0)
 
@@ -122,7 +125,7 @@ class LocalSmoothing:
                 return
             Lv = self.levels[l]
             x = self.sm[l].vmult(defect[l])
-            t = defect[l] - Lv.A @ x - Lv.A_edge_out @ x
+            t = defect[l] - Lv.A_down @ x  # mg::Matrix over MGInterfaceOperator: vmult_interface_down
             defect[l - 1] += self.P[l].T @ t
             step(l - 1)
             x = x + self.P[l] @ sol[l - 1]

@@ -51,6 +51,8 @@ def test_level_operators_edge_matrices_and_transfers(mgamd, ctx, ls_hierarchies,
         op.vmult_interface_up(dst, src)  # ref:include/operator.h:203-226
         t = Lv.A_edge_in @ x
         assert np.abs(dst.to_host() - t).max() <= 1e-13 * max(np.abs(t).max(), 1.0)
+        op.vmult_interface_down(dst, src)  # ref:include/operator.h:191-201: the matrix of Multigrid's residual step
+        assert rel_err(dst.to_host(), Lv.A_down @ x) < 1e-13
         if l > 0:
             xc, xf0 = rng.standard_normal(ref.levels[l - 1].n), rng.standard_normal(Lv.n)
             vc, vf = h.operators[l - 1].initialize_dof_vector().from_host(xc), op.initialize_dof_vector().from_host(xf0)

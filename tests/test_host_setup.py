@@ -231,3 +231,52 @@ def test_local_smoothing_level_tables(mgamd, geo, L, p):
         assert {(act_keys[a], keys[b]) for a, b in zip(g, li)} == {(s.G.keys[a], Lv.keys[b]) for a, b in zip(og, ol)}
     with pytest.raises(mgamd.MgamdError, match="level"):
         fine.level_mesh(fine.n_levels)
+
+
+def test_triangulation_from_caller_leaves(mgamd, oracle):
+    """mgamd_tria_create_from_leaves: a caller-built octree (the leaves of the independent oracle mesh generator, shuffled)
+    gives the same triangulation, DoF tables and right-hand side as the named geometry; invalid input is refused with
+    MGAMD_ERR_INVALID: gaps, overlaps, out-of-range indices, and meshes that are not 2:1 balanced across faces, edges and
+    corners."""
+    for geo, L, p in (("quadrant", 4, 2), ("annulus", 4, 1), ("hypercube", 2, 4)):
+        leaves = np.array(sorted(oracle.create_mesh(geo, L)), dtype=np.int64)  # (level, i, j, k)
+        rng = np.random.default_rng(5)
+        leaves = leaves[rng.permutation(len(leaves))]
+        t = mgamd.Triangulation.from_leaves(leaves[:, 0], leaves[:, 1], leaves[:, 2], leaves[:, 3])
+        ref = mgamd.Triangulation(geo, L)
+        assert t.n_cells == ref.n_cells and t.n_levels == ref.n_levels and t.n_cells_hn == ref.n_cells_hn
+        assert all(np.array_equal(a, b) for a, b in zip(t.cells(), ref.cells()))
+        d, dref = mgamd.DoFs(t, p, 0), mgamd.DoFs(ref, p, 0)
+        assert d.n_dofs == dref.n_dofs and np.array_equal(d.keys(), dref.keys()) and np.array_equal(d.cell_dofs(), dref.cell_dofs())
+        assert np.array_equal(d.rhs_constant(), dref.rhs_constant())
+        assert t.coarsen().n_cells == ref.coarsen().n_cells
+    one = lambda cells: mgamd.Triangulation.from_leaves(*np.array(cells, dtype=np.int64).T)
+    kids = lambda l, i, j, k: [(l + 1, 2 * i + a, 2 * j + b, 2 * k + c) for c in (0, 1) for b in (0, 1) for a in (0, 1)]
+    assert one([(0, 0, 0, 0)]).n_cells == 1
+    base = kids(0, 0, 0, 0)
+    with pytest.raises(mgamd.MgamdError, match="cover"):
+        one(base[:-1])  # gap
+    with pytest.raises(mgamd.MgamdError, match="overlap"):
+        one(base + [(2, 0, 0, 0)])  # a cell and its descendant
+    with pytest.raises(mgamd.MgamdError, match="range"):
+        one([(1, 2, 0, 0)] + base[1:])
+    # refine the corner child (1,0,0,0) twice towards the cube's centre: its grandchild at the centre touches the level-1
+    # cell (1,1,1,1) only in a CORNER -- balanced across faces and edges, not across corners
+    lvl2 = kids(1, 0, 0, 0)
+    unbalanced = [c for c in base if c != (1, 0, 0, 0)] + [c for c in lvl2 if c != (2, 1, 1, 1)] + kids(2, 1, 1, 1)
+    with pytest.raises(mgamd.MgamdError, match="2:1"):
+        one(unbalanced)
+    # corner ONLY: every level-1 cell but the diagonally opposite one (1,1,1,1) refined once, then (2,1,1,1) once more: its child
+    # at the cube's centre meets (1,1,1,1) in one vertex and is two levels finer
+    corner = [(1, 1, 1, 1)] + kids(2, 1, 1, 1)
+    for c in base:
+        if c != (1, 1, 1, 1):
+            corner += [k for k in kids(*c) if k != (2, 1, 1, 1)]
+    with pytest.raises(mgamd.MgamdError, match="2:1"):
+        one(corner)
+    # the same refinement with the neighbours refined once is fine
+    ok = [c for c in lvl2 if c != (2, 1, 1, 1)] + kids(2, 1, 1, 1)
+    for c in base:
+        if c != (1, 0, 0, 0):
+            ok += kids(*c)
+    assert one(ok).n_cells == len(ok)
