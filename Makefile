@@ -6,7 +6,7 @@ LIBDIR     := dealii_multigrid_amd/lib
 DEBUGFLAGS ?=
 HIPFLAGS   := $(DEBUGFLAGS) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wall -Wno-unused-function -Iinclude
 LIB        := $(LIBDIR)/libmgamd.so
-HDRS       := $(wildcard $(CSRC)/*.hpp) include/mgamd.h
+HDRS       := $(wildcard $(CSRC)/*.hpp) include/mgamd.h include/mgamd_dev.h
 
 BIN        := dealii_multigrid_amd/bin/multigrid_throughput
 

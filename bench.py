@@ -49,17 +49,29 @@ def algorithmic_bytes_per_vcycle(n_dofs_per_level, k=3, word=8):
     return word * ((10 * k + 3) * sum(N[1:]) + 2 * sum(N[:-1]))
 
 
-def run_workload(m, ctx, geometry, n_ref, degree, mg_type, coarse, steps, warmup, barrier, sync, profile, comm=None, details=False):
+def run_workload(m, ctx, geometry, n_ref, degree, mg_type, coarse, steps, warmup, barrier, sync, profile, comm=None, details=False,
+                 number_type=None, diagnostics=False):
     t0 = time.time()
+    number_type = m.F64 if number_type is None else number_type
+    word = 8 if number_type == m.F64 else 4
     if comm is None:
-        h = m.Hierarchy(ctx, geometry, n_ref, degree, mg_type, smoother_degree=3, coarse_solver=coarse, number_type=m.F64)
+        h = m.Hierarchy(ctx, geometry, n_ref, degree, mg_type, smoother_degree=3, coarse_solver=coarse, number_type=number_type)
     else:
         h = m.DistributedHierarchy(ctx, comm, geometry, n_ref, degree, mg_type=mg_type, smoother_degree=3, coarse_solver=coarse,
-                                   number_type=m.F64)
-    b, z = h.fine_operator.initialize_dof_vector(), h.fine_operator.initialize_dof_vector()
-    h.fine_operator.rhs(b)
+                                   number_type=number_type)
+    # PreconditionMG::vmult acts on the OUTER vectors, which are double whatever MGNumberType is (ref:multigrid_throughput.cc:
+    # 2430-2433 run<3, 1, double, MGNumber>): with float levels copy_to_mg / copy_from_mg cast
+    if number_type == m.F64:
+        b, z = h.fine_operator.initialize_dof_vector(), h.fine_operator.initialize_dof_vector()
+        h.fine_operator.rhs(b)
+    else:
+        import numpy as np
+
+        b, z = m.Vector(ctx, h.dofs[-1].n_dofs), m.Vector(ctx, h.dofs[-1].n_dofs)
+        b.from_host(np.asarray(h.dofs[-1].rhs_constant()))
     ctx.synchronize()
     setup_s = time.time() - t0
+    diag = rccl_diagnostics(m, ctx, comm, h) if (diagnostics and comm is not None) else None
     for _ in range(max(warmup, 1)):
         h.mg.vmult(z, b)
     if profile:
@@ -85,8 +97,11 @@ def run_workload(m, ctx, geometry, n_ref, degree, mg_type, coarse, steps, warmup
         N = [int(round(comm.allreduce_sum(ctx, float(op.n_owned())))) if h.distributed[l] else h.dofs[l].n_dofs
              for l, op in enumerate(h.operators)]
     res = dict(n_dofs=h.n_dofs, n_cells=h.trias[-1].n_cells, n_levels=len(N), level_dofs=N, elapsed=elapsed, setup_s=setup_s,
-               bytes_per_vcycle=algorithmic_bytes_per_vcycle(N), groups=h.dofs[-1].groups(), prof=prof,
-               coarse_solver=h.mg.coarse_solver_used())
+               bytes_per_vcycle=algorithmic_bytes_per_vcycle(N, word=word), groups=h.dofs[-1].groups(), prof=prof,
+               coarse_solver=h.mg.coarse_solver_used(),
+               fused_transfer_bricks=sum(t.n_fused_bricks() for t in h.transfers[1:] if t is not None))
+    if diag is not None:
+        res["rccl_diagnostics"] = diag
     if comm is not None:
         info = h.dofs[-1].info
         res["halo"] = dict(root_level=h.partition.root_level, peers=info.n_peers, halo_send_entries=info.n_halo_send, n_local=h.n_local)
@@ -117,6 +132,8 @@ def run_workload(m, ctx, geometry, n_ref, degree, mg_type, coarse, steps, warmup
                                  achieved_GBps=8.0 * words * N[L] / (ms[6, L] * 1e-3) / 1e9)
     # reference protocol for context: CG solve to reltol 1e-4 (ref:multigrid_throughput.cc:1238-1254); the reference's
     # own headline column throughput = n_dofs * n_iterations / time (ref:multigrid_throughput.cc:1282)
+    if number_type != m.F64:
+        return res
     x = h.fine_operator.initialize_dof_vector()
     m.solve_cg(h.fine_operator, h.mg, x, b, 1e-4)  # warm-up
     sync()
@@ -126,6 +143,43 @@ def run_workload(m, ctx, geometry, n_ref, degree, mg_type, coarse, steps, warmup
     res["cg_iterations"], res["cg_time_s"] = it, time.perf_counter() - t0
     res["cg_throughput"] = h.n_dofs * it / res["cg_time_s"]
     return res
+
+
+def rccl_diagnostics(m, ctx, comm, h, reps=20):
+    """First contact of the sharded path with real RCCL, made a diagnosis instead of one number: per rank the halo plan of the
+    finest level, a CHECKED exchange (ones on every DoF: after compress(add) a shared entry holds the number of ranks that share
+    it, known from the halo plan), and the times of one halo exchange (pack + grouped ncclSend/ncclRecv + combine) and of one
+    scalar all-reduce, host-synchronised averages over `reps` calls."""
+    import numpy as np
+
+    op, d = h.fine_operator, h.dofs[-1]
+    info = d.info
+    out = dict(rank=comm.rank, n_local_dofs=d.n_dofs, peers=int(info.n_peers), halo_send_entries=int(info.n_halo_send))
+    s = comm.allreduce_sum(ctx, float(comm.rank + 1))
+    out["allreduce_ok"] = bool(abs(s - comm.n_ranks * (comm.n_ranks + 1) / 2) < 1e-12)
+    v = op.initialize_dof_vector()
+    v.set(1.0)
+    op.exchange_add_tail(v)
+    ctx.synchronize()
+    plan = d.halo_plan() if info.n_peers else None
+    if plan is not None:
+        got = v.to_host()[info.n_interior + np.asarray(plan["sh_tail"], dtype=np.int64)]
+        want = np.diff(np.asarray(plan["sh_ptr"], dtype=np.int64)).astype(float)
+        out["exchange_ok"] = bool(np.array_equal(got, want))
+        out["shared_dofs"] = int(len(want))
+    else:
+        out["exchange_ok"] = True
+        out["shared_dofs"] = 0
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        op.exchange_add_tail(v)
+    ctx.synchronize()
+    out["exchange_us"] = (time.perf_counter() - t0) / reps * 1e6
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        comm.allreduce_sum(ctx, 1.0)
+    out["allreduce_us"] = (time.perf_counter() - t0) / reps * 1e6
+    return out
 
 
 def pmc_traffic(n_ref, B):
@@ -183,9 +237,11 @@ def host_cpu_topology():
     return use, desc
 
 
-def cpu_baseline(m, geometry, n_ref, degree, max_seconds=25.0):
-    """host-CPU baseline: the C++/OpenMP oracle ("port": deal.II cannot be built here) on a bounded sample: the largest
-    octant level that fits the budget (NRefGlobal 7, 17.6 M DoFs, 1/8 of the GPU workload), every core this job may use."""
+def cpu_baseline(m, geometry, n_ref, degree, headline_nref, max_seconds=25.0):
+    """host-CPU baseline: the C++/OpenMP oracle ("port": deal.II cannot be built here; a scalar-per-cell restatement, well below
+    what deal.II's cell-batch SIMD does) on a bounded sample of the SAME workload: by default the headline configuration itself
+    (NRefGlobal 8, 137 M DoFs, a few V-cycles), every core this job may use; the library is rebuilt on this host when it was
+    compiled for another CPU (oracle/cpu_oracle.py)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import cpu_oracle
 
@@ -202,17 +258,18 @@ def cpu_baseline(m, geometry, n_ref, degree, max_seconds=25.0):
     out = dict(value=dofs[-1].n_dofs / t, unit="DoF/s", cores=cpu_oracle.num_threads(), kind="port",
                sample=f"{n} V-cycles of {geometry} NRefGlobal={n_ref} p={degree} ({dofs[-1].n_dofs} DoFs), C++/OpenMP oracle "
                       f"(host restatement of the reference's CPU path, not deal.II), {t*1e3:.1f} ms/cycle",
+               config_matches_headline=bool(n_ref == headline_nref), built_for_this_host=cpu_oracle.built_for_this_host(),
                host=desc, host_cpus=os.cpu_count())
-    # the single-core figure next to it, on the next coarser octant (a 1-core cycle of the sample takes too long)
+    # the single-core figure next to it, on a coarser octant (a 1-core cycle of the sample takes too long)
     del levels, transfers, mg
-    dofs1 = dofs[:-1]
+    dofs1 = dofs[:-1] if n_ref <= 7 else dofs[:-2]
     levels, transfers, mg = cpu_oracle.build_from_dofs(dofs1, m.transfer_tables, coarse="direct")
     cpu_oracle.set_num_threads(1)
     b1 = dofs1[-1].rhs_constant()
     t_one = mg.time_vcycles(b1, 2)
     cpu_oracle.set_num_threads(cores)
     out["value_1core"] = dofs1[-1].n_dofs / t_one
-    out["sample_1core"] = f"2 V-cycles of {geometry} NRefGlobal={n_ref - 1} p={degree} ({dofs1[-1].n_dofs} DoFs), 1 thread"
+    out["sample_1core"] = f"2 V-cycles of {geometry} NRefGlobal={n_ref - (1 if n_ref <= 7 else 2)} p={degree} ({dofs1[-1].n_dofs} DoFs), 1 thread"
     return out
 
 
@@ -222,20 +279,24 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="octant_p4")
-    ap.add_argument("--nref", type=int, default=None, help="NRefGlobal of the primary workload (default: 8)")
+    ap.add_argument("--nref", type=int, default=None, help="NRefGlobal of the primary workload (default: octant_p4 8 -- 9 = 1.1 G DoFs is the "
+                    "weak-scaling companion for 8 GPUs; pmg_annulus: 9 on one GPU (149 M DoFs), 8 sharded)")
     ap.add_argument("--nref-p1", type=int, default=9, help="NRefGlobal of the secondary octant p=1 workload")
     ap.add_argument("--nref-uniform-p1", type=int, default=9, help="NRefGlobal of the uniform-mesh p=1 workload (135 M DoFs)")
-    ap.add_argument("--cpu-nref", type=int, default=7, help="NRefGlobal of the CPU-baseline sample")
+    ap.add_argument("--cpu-nref", type=int, default=8, help="NRefGlobal of the CPU-baseline sample (default: the headline configuration)")
+    ap.add_argument("--no-float", action="store_true", help="skip the MGNumberType float figure (also_float)")
     ap.add_argument("--coarse", default=None, help="CoarseGridSolverType override (pmg_annulus: cg_with_chebyshev | cg | amg = geometric stand-in)")
     ap.add_argument("--mode", choices=["sharded", "replicas"], default="sharded", help="N > 1: domain decomposition (default) or replicas")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
     geometry, nref_default, degree, mg_type, coarse, cfg_name = WORKLOADS[args.workload]
-    nref = args.nref if args.nref is not None else nref_default
     coarse = args.coarse or coarse
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.workload == "pmg_annulus" and world == 1:
+        nref_default = 9  # fills one GPU (149 M DoFs); NRefGlobal 8 (18.6 M) is the size quoted for 8 GPUs and is printed beside it
+    nref = args.nref if args.nref is not None else nref_default
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
@@ -267,7 +328,7 @@ def main():
             dist.broadcast(uid, 0)
             comm = m.Communicator.rccl(ctx, world, rank, bytes(uid.cpu().numpy().tobytes()))
         prim = run_workload(m, ctx, geometry, nref, degree, mg_type, coarse, args.steps, args.warmup, barrier, sync, profile=True, comm=comm,
-                            details=world == 1)
+                            details=world == 1, diagnostics=True)
     except Exception as e:  # noqa: BLE001
         # no fallback, no relabelled metric: the other ranks may be blocked inside a collective, so leave hard with a
         # non-zero status and let the launcher tear the job down
@@ -316,8 +377,17 @@ def main():
     }
     if "ms_no_collapse" in prim:
         out["ms_per_step_no_collapse"] = prim["ms_no_collapse"]
+    out["config"]["fused_transfer_bricks"] = prim["fused_transfer_bricks"]
     if "halo" in prim:
         out["config"]["halo_rank0"] = prim["halo"]
+    if "rccl_diagnostics" in prim:
+        # every rank's view (halo plan sizes, checked exchange, exchange / all-reduce times), gathered on rank 0
+        gathered = [None] * world
+        dist.all_gather_object(gathered, prim["rccl_diagnostics"])
+        out["rccl_diagnostics"] = gathered
+        if not all(g["exchange_ok"] and g["allreduce_ok"] for g in gathered):
+            print(f"bench.py: RCCL self-check failed: {gathered}", file=sys.stderr, flush=True)
+            os._exit(3)
     # whole-V-cycle roofline figure (against the aggregate HBM bandwidth of the GPUs used) and the dominant kernel's
     vcycle_gbs = (world if mode == "replicas" else 1) * prim["bytes_per_vcycle"] / (elapsed / args.steps) / 1e9 / world
     out["vcycle_algorithmic_GBps_per_gpu"] = vcycle_gbs
@@ -377,8 +447,29 @@ def main():
                                       "unit": "DoF/s", "n_gpus": 1, "ms_per_step": tu * 1e3, "n_dofs": uni["n_dofs"],
                                       "NRefGlobal": args.nref_uniform_p1, "vcycle_frac_of_hbm_peak": uni["bytes_per_vcycle"] / tu / 1e9 / HBM_PEAK_GBS,
                                       "cg_iterations_reltol_1e-4": uni["cg_iterations"]}
+    if world == 1 and args.workload == "octant_p4" and not args.no_float:
+        # MGNumberType "float" is the reference's default (ref:scripts/default.json:16, ref:multigrid_throughput.cc:2430-2433): the
+        # same hierarchy with FP32 level vectors under the FP64 outer vectors (copy_to_mg / copy_from_mg cast); 4-byte words in
+        # the byte model.  Its own line: a different dtype, never mixed into `value`.
+        flt = run_workload(m, ctx, geometry, nref, degree, mg_type, coarse, max(args.steps // 2, 3), 2, lambda: None, sync, profile=False,
+                           number_type=m.F32)
+        tf = flt["elapsed"] / max(args.steps // 2, 3)
+        out["also_float"] = {"metric": f"DoF/s per V-cycle, 3D octant p={degree}, MGNumberType float (FP32 levels under FP64 CG vectors)",
+                             "value": flt["n_dofs"] / tf, "unit": "DoF/s", "n_gpus": 1, "ms_per_step": tf * 1e3, "dtype": "f32",
+                             "n_dofs": flt["n_dofs"], "NRefGlobal": nref, "bytes_model": "SURVEY 8(d) with 4-byte words",
+                             "vcycle_frac_of_hbm_peak": flt["bytes_per_vcycle"] / tf / 1e9 / HBM_PEAK_GBS,
+                             "fused_transfer_bricks": flt["fused_transfer_bricks"],
+                             "note": "p = 4 float runs the one-workgroup-per-brick kernels (the persistent Chebyshev instantiation spills in "
+                                     "float at p = 4), without fused transfers"}
+    if world == 1 and args.workload == "pmg_annulus" and nref != 8 and not args.no_secondary:
+        # the size BASELINE.json configs[4] shards over 8 GPUs, on one GPU for reference
+        sm = run_workload(m, ctx, geometry, 8, degree, mg_type, coarse, args.steps, args.warmup, lambda: None, sync, profile=False)
+        ts = sm["elapsed"] / args.steps
+        out["also_sharded_size"] = {"metric": out["metric"], "value": sm["n_dofs"] / ts, "unit": "DoF/s", "n_gpus": 1, "ms_per_step": ts * 1e3,
+                                    "n_dofs": sm["n_dofs"], "NRefGlobal": 8, "coarse_solver": sm["coarse_solver"],
+                                    "cg_iterations_reltol_1e-4": sm["cg_iterations"]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(m, "quadrant", args.cpu_nref, 4)
+        out["cpu_baseline"] = cpu_baseline(m, "quadrant", args.cpu_nref, 4, nref if args.workload == "octant_p4" else -1)
     barrier()
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -443,6 +443,10 @@ class Operator:
         """local-smoothing level: the edge matrix, A with the refinement-edge DoFs unconstrained applied to src|edge"""
         _chk(_lib.mgamd_level_op_vmult_interface_up(self._h, dst._h, src._h))
 
+    def exchange_add_tail(self, v: Vector):
+        """distributed level: the shared entries of v become the sum over the sharing ranks (compress(add))"""
+        _chk(_lib.mgamd_level_op_exchange_add_tail(self._h, v._h))
+
     def vmult_interface_down(self, dst: Vector, src: Vector):
         """Operator::vmult_interface_down: the plain cell loop (refinement-edge DoFs as ordinary DoFs), identity on the
         constrained rows -- the matrix of Multigrid's residual step (MGInterfaceOperator::vmult)"""

@@ -1,6 +1,7 @@
 // Shared definitions of the opaque C-ABI handles and the exception -> status translation.
 #pragma once
 #include "../../include/mgamd.h"
+#include "../../include/mgamd_dev.h"
 #include "level_tables.hpp"
 #include "transfer_tables.hpp"
 #include "partition.hpp"

@@ -601,6 +601,15 @@ mgamd_mg_create_local_smoothing(mgamd_ctx *ctx, unsigned n_levels, mgamd_level_o
 }
 
 int
+mgamd_level_op_exchange_add_tail(mgamd_level_op *op, mgamd_vec *v)
+{
+  MGAMD_TRY
+  REQUIRE(op && v);
+  op->op->exchange_add_tail(*v);
+  MGAMD_CATCH
+}
+
+int
 mgamd_level_op_vmult_interface_up(mgamd_level_op *op, mgamd_vec *dst, const mgamd_vec *src)
 {
   MGAMD_TRY

@@ -41,6 +41,20 @@ namespace mgamd
       h.reset(t, mgamd_tria_destroy);
       query();
     }
+    // a caller-built octree over one root cell (the active cells of a parallel::distributed::Triangulation as (level, i, j, k));
+    // checked for exact tiling and full 2:1 balance (mgamd_tria_create_from_leaves)
+    static std::shared_ptr<Triangulation>
+    from_leaves(const std::vector<uint8_t> &level, const std::vector<uint32_t> &i, const std::vector<uint32_t> &j, const std::vector<uint32_t> &k)
+    {
+      if (level.size() != i.size() || level.size() != j.size() || level.size() != k.size())
+        throw std::runtime_error("from_leaves: arrays of different lengths");
+      mgamd_tria *t = nullptr;
+      check(mgamd_tria_create_from_leaves(level.size(), level.data(), i.data(), j.data(), k.data(), &t));
+      auto r = std::shared_ptr<Triangulation>(new Triangulation());
+      r->h.reset(t, mgamd_tria_destroy);
+      r->query();
+      return r;
+    }
     // one step of MGTransferGlobalCoarseningTools::create_geometric_coarsening_sequence
     std::shared_ptr<Triangulation>
     coarsen() const

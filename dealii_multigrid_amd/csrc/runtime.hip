@@ -1068,8 +1068,18 @@ namespace mgamd
     unsigned
     set_collapse(bool on) override
     {
+      if (collapse_enabled != on)
+        drop_graph(); // a captured cycle replays the work enqueued under the old setting
       collapse_enabled = on;
       return collapse_level;
+    }
+    void
+    drop_graph()
+    {
+      if (graph_exec)
+        (void)hipGraphExecDestroy(graph_exec);
+      graph_exec = nullptr;
+      graph_z = graph_r = nullptr;
     }
     DBuf<T>                          cg_r, cg_z, cg_p, cg_Ap;
     DBuf<double>                     cg_S; // device scalars of the coarse CG (device_pcg)

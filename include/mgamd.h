@@ -210,6 +210,10 @@ int mgamd_level_op_create_distributed(mgamd_ctx *ctx, const mgamd_dofs *dofs, in
 int mgamd_level_op_destroy(mgamd_level_op *op);
 /* inner product over the GLOBAL vector (every DoF counted once across ranks) */
 int mgamd_level_op_dot(mgamd_level_op *op, const mgamd_vec *x, const mgamd_vec *y, double *result);
+/* the export half of MatrixFree::cell_loop's ghost exchange on a distributed level (LinearAlgebra::distributed::Vector::
+ * compress(VectorOperation::add), ref:include/operator.h:166-167): the entries of shared DoFs of v become the sum over the
+ * sharing ranks, identical on all of them; stream-ordered; no-op on a level that is not distributed.  bench.py times it. */
+int mgamd_level_op_exchange_add_tail(mgamd_level_op *op, mgamd_vec *v);
 /* number of DoFs this rank owns (sums to DoFHandler::n_dofs() over the ranks) */
 int mgamd_level_op_n_owned(const mgamd_level_op *op, uint64_t *n);
 int mgamd_level_op_m(const mgamd_level_op *op, uint64_t *n); /* Operator::m (ref:include/operator.h:123) */
@@ -224,10 +228,6 @@ int mgamd_level_op_rhs(mgamd_level_op *op, mgamd_vec *rhs);
 /* the same for SimulationType `kind` (see mgamd_dofs_rhs), and constraints.distribute(solution) after the solve */
 int mgamd_level_op_rhs_kind(mgamd_level_op *op, int kind, mgamd_vec *rhs);
 int mgamd_level_op_distribute(mgamd_level_op *op, int kind, mgamd_vec *x);
-
-/* development aid: with MGAMD_STAMPS=<mode> in the environment the largest slot group's kernel of that mode
- * records 8 wall-clock stamps (10 ns ticks) per workgroup at its phase boundaries; returns them */
-int mgamd_level_op_debug_stamps(mgamd_level_op *op, unsigned long long *out, uint64_t max_count, uint64_t *count);
 
 /* PreconditionChebyshev (ref:multigrid_throughput.cc:849-852, 867-883): the inverse diagonal is
  * computed internally (DiagonalMatrix preconditioner); eigenvalues are estimated at creation with
@@ -317,17 +317,6 @@ int mgamd_mg_time_vcycles(mgamd_mg *mg, mgamd_vec *z, const mgamd_vec *r, unsign
  * 1625-1635): solves A x = b from x = 0; returns last_step() and the final residual norm. */
 int mgamd_solve_cg(mgamd_level_op *A, mgamd_mg *preconditioner, mgamd_vec *x, const mgamd_vec *b, double reltol, double abstol,
                    unsigned maxiter, unsigned *n_iterations, double *residual_norm);
-
-/* per-kernel device time of the dominant kernel (cell operator) accumulated since the last reset,
- * measured with HIP events when profiling is enabled (bench.py roofline.achieved) */
-int mgamd_ctx_kernel_profile(mgamd_ctx *ctx, int enable);
-/* which launches are measured: brick_size = 0 (default) the slot group with the most work on every level;
- * brick_size = B only groups of B^3-cell bricks, i.e. the launches of ONE kernel symbol (what rocprofv3 averages) */
-int mgamd_ctx_kernel_profile_brick(mgamd_ctx *ctx, int brick_size);
-int mgamd_ctx_kernel_profile_read(mgamd_ctx *ctx, double *total_ms, uint64_t *n_launches, double *algorithmic_bytes);
-/* the bytes the measured launches are written to move themselves (the slot-interior D^-1 is evaluated in closed form by the
- * p = 1 and the persistent 17-point lattice kernels, one word less than SURVEY 8(d)'s figure in `algorithmic_bytes`) */
-int mgamd_ctx_kernel_profile_bytes_moved(mgamd_ctx *ctx, double *bytes_moved);
 
 #ifdef __cplusplus
 }

@@ -25,11 +25,33 @@ def _cpu_share():
     return n
 
 
+def _host_cpu_flags():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("flags"):
+                return " ".join(sorted(line.split(":", 1)[1].split()))
+    except Exception:
+        pass
+    return "unknown"
+
+
 def _load():
     if "OMP_NUM_THREADS" not in os.environ:
         os.environ["OMP_NUM_THREADS"] = str(min(_cpu_share(), 16))  # gpurun box: 16 CPUs per GPU
-    if not os.path.exists(_SO):
-        subprocess.check_call(["make", "-C", _HERE])
+    # the library is built with -march=native: a copy that travelled from another host (the build container -> the GPU box) is
+    # rebuilt here when the CPU's feature flags differ from the ones it was built on (3 s), so that the cpu_baseline is timed on
+    # code generated for THIS host
+    stamp = os.path.join(_HERE, "_build", "cpu_flags.txt")
+    flags = _host_cpu_flags()
+    stale = not os.path.exists(_SO) or not os.path.exists(stamp) or open(stamp).read() != flags
+    if stale:
+        try:
+            subprocess.check_call(["make", "-B", "-C", _HERE], stdout=subprocess.DEVNULL)
+            with open(stamp, "w") as f:
+                f.write(flags)
+        except Exception:
+            if not os.path.exists(_SO):
+                raise
     lib = C.CDLL(_SO)
     lib.mgo_level_create.restype = C.c_void_p
     lib.mgo_transfer_create.restype = C.c_void_p
@@ -48,6 +70,12 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def built_for_this_host():
+    """True if the loaded library was compiled on a host with this host's CPU feature flags (see _load)"""
+    stamp = os.path.join(_HERE, "_build", "cpu_flags.txt")
+    return os.path.exists(stamp) and open(stamp).read() == _host_cpu_flags()
+
+
 def num_threads():
     return _lib.mgo_num_threads()
 
@@ -57,13 +85,20 @@ def set_num_threads(n):
 
 
 class CpuLevel:
-    def __init__(self, dofs):
-        """dofs: dealii_multigrid_amd.DoFs (only its exported tables are used)."""
-        self.p = dofs.degree
-        self.n = dofs.n_dofs
-        cd = np.ascontiguousarray(dofs.cell_dofs())
-        lev, _, _, _, mask = dofs.tria.cells()
-        first_c = dofs.info.n_interior + dofs.info.n_tail
+    def __init__(self, dofs=None, tables=None):
+        """dofs: dealii_multigrid_amd.DoFs (only its exported tables are used); or tables: own_tables.LevelTables (the
+        oracle's own mesh, numbering and gather lists: nothing of the product involved)."""
+        if tables is not None:
+            self.p, self.n = tables.p, tables.n
+            cd = np.ascontiguousarray(tables.cell_dofs, dtype=np.uint32)
+            lev, mask = np.ascontiguousarray(tables.level, np.uint8), np.ascontiguousarray(tables.mask, np.uint16)
+            first_c = tables.first_constrained
+        else:
+            self.p = dofs.degree
+            self.n = dofs.n_dofs
+            cd = np.ascontiguousarray(dofs.cell_dofs())
+            lev, _, _, _, mask = dofs.tria.cells()
+            first_c = dofs.info.n_interior + dofs.info.n_tail
         self._h = C.c_void_p(
             _lib.mgo_level_create(self.p, C.c_uint64(cd.shape[0]), C.c_uint32(self.n), C.c_uint32(first_c), _p(cd), _p(lev), _p(mask))
         )
@@ -149,6 +184,29 @@ class CpuMultigrid:
         if getattr(self, "_h", None):
             _lib.mgo_mg_destroy(self._h)
             self._h = None
+
+
+def build_from_own_tables(geometry, n_ref, degree, mg_type="HMG-global", smoother_degree=3, coarse="direct", numbering_keys=None):
+    """the whole hierarchy from the oracle's own tables (own_tables.py): meshes from mgoracle.create_mesh / coarsening_sequence,
+    the oracle's numbering (or the DoF labels numbering_keys[level], see own_tables.LevelTables).  Returns (tables per level,
+    levels, transfers, multigrid)."""
+    import mgoracle as o
+    import own_tables as ot
+
+    fine = o.create_mesh(geometry, n_ref)
+    if mg_type == "HMG-global":
+        spaces = [(m, degree) for m in o.coarsening_sequence(fine)]
+    elif mg_type == "PMG":
+        seq = [degree]
+        while seq[-1] > 1:
+            seq.append(max(seq[-1] // 2, 1))
+        spaces = [(fine, p) for p in seq[::-1]]
+    else:
+        raise ValueError(mg_type)
+    tabs = [ot.LevelTables(m, p, None if numbering_keys is None else numbering_keys[l]) for l, (m, p) in enumerate(spaces)]
+    levels = [CpuLevel(tables=t) for t in tabs]
+    transfers = [None] + [CpuTransfer(levels[l], levels[l - 1], ot.transfer_tables(tabs[l], tabs[l - 1])) for l in range(1, len(levels))]
+    return tabs, levels, transfers, CpuMultigrid(levels, transfers, smoother_degree, coarse=coarse)
 
 
 def build_from_dofs(dofs_list, transfer_tables_fn, smoother_degree=3, coarse="direct"):

@@ -41,3 +41,43 @@ def test_solve_matches_cpu_oracle(mgamd, ctx, geo, L, p, typ):
     xs, its, ress = mg.solve_cg(b.to_host(), 1e-4)
     assert it == its
     assert rel_err(x.to_host(), xs) < (1e-10 if coarse == "amg" else 1e-5)
+
+
+@pytest.mark.parametrize("geo,L,p,typ", [("quadrant", 5, 4, "HMG-global"), ("annulus", 6, 2, "HMG-global"), ("quadrant", 6, 1, "HMG-global"),
+                                         ("annulus", 5, 4, "PMG")])
+def test_solve_matches_cpu_oracle_on_the_oracles_own_tables(mgamd, ctx, geo, L, p, typ):
+    """The same comparison with NOTHING of the product's host setup on the checker's side: mesh, coarsening sequence, DoF
+    classification, constraint masks, gather lists and transfer patches come from oracle/own_tables.py (pure Python on
+    mgoracle's octree).  Only the DoF LABELS are the product's (its geometric key list per level), so that deal.II's
+    numbering-dependent Chebyshev start vector (i mod 11) - mean is the same vector on both sides and the tolerances can stay at
+    rounding level.  321 k DoFs at p = 4: 27 bricks of 17^3 lattice points with fused transfers next to constrained families
+    and hanging single cells."""
+    import cpu_oracle
+
+    coarse = "amg" if typ == "HMG-global" else "cg_with_chebyshev"
+    h = mgamd.Hierarchy(ctx, geo, L, p, typ, coarse_solver=coarse, max_brick=0)
+    tabs, levels, transfers, mg = cpu_oracle.build_from_own_tables(geo, L, p, typ, coarse=coarse, numbering_keys=[d.keys() for d in h.dofs])
+    for d, t in zip(h.dofs, tabs):
+        assert t.n == d.n_dofs and t.first_constrained == d.info.n_interior + d.info.n_tail
+        assert int(t.dirichlet.sum()) == d.info.n_dirichlet
+    rng = np.random.default_rng(17)
+    for l, op in enumerate(h.operators):
+        x = rng.standard_normal(tabs[l].n)
+        src, dst = op.initialize_dof_vector().from_host(x), op.initialize_dof_vector()
+        op.vmult(dst, src)
+        assert rel_err(dst.to_host(), levels[l].vmult(x)) < 1e-13
+        assert h.smoothers[l].eigenvalue_estimates()[1] == pytest.approx(mg.max_eigenvalue(l), rel=1e-9)
+    n = h.n_dofs
+    r = rng.standard_normal(n)
+    vr, vz = mgamd.Vector(ctx, n).from_host(r), mgamd.Vector(ctx, n)
+    h.mg.vmult(vz, vr)
+    assert rel_err(vz.to_host(), mg.vcycle(r)) < (1e-11 if coarse == "amg" else 1e-5)
+    b, x = h.fine_operator.initialize_dof_vector(), h.fine_operator.initialize_dof_vector()
+    h.fine_operator.rhs(b)
+    bo = tabs[-1].rhs_constant()
+    bo[tabs[-1].first_constrained:] = 0.0
+    assert rel_err(b.to_host(), bo) < 1e-13
+    it, res = mgamd.solve_cg(h.fine_operator, h.mg, x, b, 1e-4)
+    xs, its, ress = mg.solve_cg(bo, 1e-4)
+    assert it == its
+    assert rel_err(x.to_host(), xs) < (1e-10 if coarse == "amg" else 1e-5)

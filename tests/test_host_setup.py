@@ -18,6 +18,10 @@ def test_c_abi_exports_every_declared_symbol(mgamd):
     hdr = open(os.path.join(ROOT, "include", "mgamd.h")).read()
     names = sorted(set(re.findall(r"\b(mgamd_[a-z0-9_]+)\s*\(", hdr)))
     assert len(names) > 40
+    # the boundary header carries no development entry points; those live in mgamd_dev.h (and are exported too)
+    assert not [n for n in names if "profile" in n or "debug" in n]
+    dev = sorted(set(re.findall(r"\b(mgamd_[a-z0-9_]+)\s*\(", open(os.path.join(ROOT, "include", "mgamd_dev.h")).read())))
+    assert len(dev) >= 5 and not [n for n in dev if not hasattr(mgamd._lib, n)]
     missing = [n for n in names if not hasattr(mgamd._lib, n)]
     assert not missing, missing
 
