@@ -71,7 +71,9 @@ namespace mgamd
     return B == 2 || (constr && B > 2);
   }
 
-  template <int P, int B>
+  // THREADS: the threads that share one set of slots: a 256-thread workgroup, or ONE WAVE (64) for the wave-scoped single-cell
+  // path (lattice_apply_body<..., WAVE = true>), where every wave of a workgroup works on its own cells without workgroup barriers
+  template <int P, int B, int THREADS = 256>
   struct Geo
   {
     static constexpr int N       = P * B + 1;
@@ -80,7 +82,7 @@ namespace mgamd
     static constexpr int N_INT   = NI > 0 ? NI * NI * NI : 0;
     static constexpr int N_SHELL = N3 - N_INT;
     static constexpr int LINES   = N * N;
-    static constexpr int SPW     = LINES >= 256 ? 1 : 256 / LINES;
+    static constexpr int SPW     = LINES >= THREADS ? 1 : THREADS / LINES;
     static constexpr int BLOCK   = ((SPW * LINES + 63) / 64) * 64;
     // the operator kernel never uses more than 4 waves: two workgroups of 4 waves fit one CU with up to
     // 256 VGPRs each, whereas two 5-wave workgroups need 4 waves on one SIMD (<= 128 VGPRs).  Lines beyond
@@ -469,6 +471,22 @@ namespace mgamd
   // line sit in adjacent lanes of ONE wavefront and update the line in place: every lane has read its inputs before any
   // lane writes (lock step, LDS operations of a wave complete in order; seg_fence() keeps the compiler from sinking a
   // load below the stores).
+  // barrier among the threads that share a set of slots: the workgroup, or -- WAVE -- one wavefront, whose LDS operations
+  // are issued and completed in order (no s_barrier: only the compiler must not move LDS accesses across it)
+  template <bool WAVE>
+  __device__ __forceinline__ void
+  slot_sync()
+  {
+    if constexpr (WAVE)
+      {
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+      }
+    else
+      __syncthreads();
+  }
+
   __device__ __forceinline__ void
   seg_fence()
   {
@@ -531,12 +549,12 @@ namespace mgamd
   };
   // before_x: called between the y and the x sweep (the x sweep holds one line less in registers than the y sweep: the
   // persistent kernel requests its epilogue operands there)
-  template <typename T, int P, int B, int BLOCK, typename Hook = NoHook, bool STREAMED = false, bool PREFETCH = false>
+  template <typename T, int P, int B, int BLOCK, typename Hook = NoHook, bool STREAMED = false, bool PREFETCH = false, bool WAVE = false>
   __device__ __forceinline__ void
   lattice_sweeps(T *__restrict__ bufA, T *__restrict__ bufB, const Mats<P> &m, int tid, int nslots, const double *__restrict__ hslot,
                  const Hook &before_x = Hook(), const bool h_is_mine = false) // h_is_mine: hslot[0] is the h of THIS thread's line
   {
-    using G              = Geo<P, B>;
+    using G              = Geo<P, B, WAVE ? 64 : 256>;
     constexpr int N      = G::N;
     constexpr int N3     = G::N3;
     constexpr int TOT    = G::SPW * G::LINES;
@@ -592,7 +610,7 @@ namespace mgamd
                 bufB[base + i * N * N] = o2[i];
               }
         }
-    __syncthreads();
+    slot_sync<WAVE>();
     // y sweep: line = (x=u, z=v):  c = My a ; g = Ky a + My b
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r)
@@ -643,7 +661,7 @@ namespace mgamd
                 bufB[base + i * N] = o2[i];
               }
         }
-    __syncthreads();
+    slot_sync<WAVE>();
     before_x();
     // x sweep: line = (y=u, z=v): out = h (Kx c + Mx g)
 #pragma unroll
@@ -690,13 +708,13 @@ namespace mgamd
             if (i < 4 || sg_s == 3)
               bufA[base + i] = h * o2[i];
         }
-    __syncthreads();
+    slot_sync<WAVE>();
   }
 
   // In-cell hanging-node interpolation (transpose = false, before the sweeps) or its transpose
   // (after), for single-cell slots (N = P+1).  One thread per line; only lines on hanging
   // faces/edges do work.  Ends with a barrier.
-  template <typename T, int P>
+  template <typename T, int P, bool WAVE = false>
   __device__ __forceinline__ void
   hanging_passes(T *__restrict__ buf, const Mats<P> &m, int sl, int u, int v, bool act, uint32_t mask, bool transpose)
   {
@@ -758,7 +776,7 @@ namespace mgamd
             for (int i = 0; i < N; ++i)
               buf[base + i * stride] = out[i];
           }
-        __syncthreads();
+        slot_sync<WAVE>();
       }
   }
 
@@ -999,10 +1017,10 @@ namespace mgamd
 
   // Interior-slot bookkeeping shared by the gather and the epilogue of lattice_apply_kernel: thread `tid`
   // handles interior entries idx = tid + it*BLOCK, it < ITER, of the workgroup's slots.
-  template <int P, int B>
+  template <int P, int B, int THREADS = 256>
   struct InteriorMap
   {
-    using G                   = Geo<P, B>;
+    using G                   = Geo<P, B, THREADS>;
     static constexpr int NI_  = G::NI > 0 ? G::NI : 1;
     static constexpr int NIN_ = G::N_INT > 0 ? G::N_INT : 1;
     static constexpr int ITER = (G::SPW * NIN_ + G::ABLOCK - 1) / G::ABLOCK;
@@ -1038,12 +1056,18 @@ namespace mgamd
   // waves per SIMD: 2 for the 17^3 lattices (<= 256 VGPRs); 6 for single-cell slots (<= 80 VGPRs, measured 5 % faster at
   // p = 4 than unconstrained with 110 VGPRs)
   // the work of workgroup `block` of `nblocks` on the slots of args.g (kernels below)
-  template <typename T, int P, int B, int MODE, bool CONSTR = false>
+  // WAVE (single-cell slots only): the slots are shared by ONE WAVEFRONT instead of a workgroup -- `block` / `nblocks` then count
+  // wavefronts, smem_raw is the wavefront's own region, and every barrier below is a compiler-level fence (slot_sync): the nine
+  // dependent phases of a hanging cell (three interpolation passes, three sweeps, three transposed passes) cost an LDS round
+  // trip each instead of a workgroup barrier with the slowest of four waves (measured with tools/stamps.py on the
+  // workgroup-scoped kernel: 5-7 of the 9 us a workgroup lives are spent between those barriers).
+  template <typename T, int P, int B, int MODE, bool CONSTR = false, bool WAVE = false>
   __device__ __forceinline__ void
   lattice_apply_body(const ApplyArgs<T, P> &args, const uint32_t block, const uint32_t nblocks, unsigned char *smem_raw)
   {
-    using G  = Geo<P, B>;
-    using IM = InteriorMap<P, B>;
+    static_assert(!WAVE || (B == 1 && !CONSTR), "wave-scoped slots: single cells");
+    using G  = Geo<P, B, WAVE ? 64 : 256>;
+    using IM = InteriorMap<P, B, WAVE ? 64 : 256>;
     T *bufA = reinterpret_cast<T *>(smem_raw);
     T *bufB = bufA + G::SPW * G::N3;
 
@@ -1051,8 +1075,8 @@ namespace mgamd
     constexpr int ITER  = IM::ITER;
     constexpr int ITERS = (G::SPW * G::N_SHELL + BLOCK - 1) / BLOCK;
 
-    const int tid    = threadIdx.x;
-    const int slot0  = (int)xcd_contiguous(block, nblocks) * G::SPW;
+    const int tid    = WAVE ? (int)(threadIdx.x & 63u) : (int)threadIdx.x;
+    const int slot0  = (int)(WAVE ? block : xcd_contiguous(block, nblocks)) * G::SPW; // (WAVE: the caller has mapped the wavefront)
     const int nslots = min((int)G::SPW, (int)args.g.n_slots - slot0);
     MGAMD_STAMP(0)
     // per-slot scalars of this thread's line (hanging-node mask, constraint mask, cell size): requested with the gather, not
@@ -1114,7 +1138,7 @@ namespace mgamd
           }
         for (int t = tid; t < nslots; t += BLOCK)
           dtab[2 * P3 + t] = T(1) / T(args.g.h[slot0 + t]);
-        __syncthreads();
+        slot_sync<WAVE>();
       }
 
     // ---- gather: addresses ----------------------------------------------------------------------------
@@ -1249,16 +1273,16 @@ namespace mgamd
               bufA[l] = xg[it];
           }
       }
-    __syncthreads();
+    slot_sync<WAVE>();
     MGAMD_STAMP(1)
 
     // ---- hanging-node interpolation (single-cell slots only) ---------------------------------------------
     bool any_hanging = false;
     if (B == 1)
       {
-        any_hanging = __syncthreads_or((int)(mask >> 3)) != 0 && !MGAMD_ABLATED(32);
+        any_hanging = (WAVE ? __any((int)(mask >> 3)) : __syncthreads_or((int)(mask >> 3))) != 0 && !MGAMD_ABLATED(32);
         if (any_hanging)
-          hanging_passes<T, P>(bufA, args.m, sl, u, v, act, mask, false);
+          hanging_passes<T, P, WAVE>(bufA, args.m, sl, u, v, act, mask, false);
       }
 
     // Which bricks may be constrained (must match LevelTables::build): families (B = 2) at every degree; larger bricks at
@@ -1276,13 +1300,13 @@ namespace mgamd
     if (!MGAMD_ABLATED(1))
       {
         if constexpr (G::ROUNDS == 1)
-          lattice_sweeps<T, P, B, BLOCK>(bufA, bufB, args.m, tid, nslots, &h_mine, NoHook(), true);
+          lattice_sweeps<T, P, B, BLOCK, NoHook, false, false, WAVE>(bufA, bufB, args.m, tid, nslots, &h_mine, NoHook(), true);
         else
-          lattice_sweeps<T, P, B, BLOCK>(bufA, bufB, args.m, tid, nslots, args.g.h + slot0);
+          lattice_sweeps<T, P, B, BLOCK, NoHook, false, false, WAVE>(bufA, bufB, args.m, tid, nslots, args.g.h + slot0);
       }
 
     if (B == 1 && any_hanging)
-      hanging_passes<T, P>(bufA, args.m, sl, u, v, act, mask, true);
+      hanging_passes<T, P, WAVE>(bufA, args.m, sl, u, v, act, mask, true);
     if constexpr (brick_may_be_constrained(B, CONSTR))
       if (any_hanging)
         brick_constraint_passes<T, P, B, BLOCK>(bufA, args.m, tid, nslots, args.g.fmask + slot0, true, G::ROUNDS == 1 ? &fm_line : nullptr);
@@ -1323,7 +1347,7 @@ namespace mgamd
     if (args.stamps)
       {
         __builtin_amdgcn_s_waitcnt(0); // drain this wave's memory operations before the final stamp
-        __syncthreads();
+        slot_sync<WAVE>();
         MGAMD_STAMP(4)
       }
 #endif
@@ -1808,6 +1832,35 @@ namespace mgamd
     lattice_apply_body<T, P, B, MODE, CONSTR>(args, blockIdx.x, gridDim.x, smem_raw);
   }
 
+  // single cells, WAVE-SCOPED: a 256-thread workgroup = four wavefronts with their own cells (64 / (p+1)^2 cells each) and their
+  // own LDS regions; no workgroup barrier anywhere (lattice_apply_body, WAVE)
+  constexpr int CELL_WAVES = 4;
+  template <typename T, int P>
+  constexpr size_t
+  cell_wave_lds()
+  {
+    using G = Geo<P, 1, 64>;
+    return (((2 * (size_t)G::SPW * G::N3 + 2 * P * P * P + G::SPW) * sizeof(T) + 15) / 16) * 16;
+  }
+  template <typename T, int P, int MODE>
+  __device__ __forceinline__ void
+  cell_waves_body(const ApplyArgs<T, P> &args, const uint32_t block, const uint32_t nblocks, unsigned char *smem_raw)
+  {
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t n_w  = (args.g.n_slots + Geo<P, 1, 64>::SPW - 1) / Geo<P, 1, 64>::SPW; // wavefronts with work
+    // workgroups in XCD-contiguous (Morton) ranges like every other kernel, the four wavefronts of one on neighbouring cells
+    const uint32_t vb = xcd_contiguous(block, nblocks) * CELL_WAVES + wave;
+    if (vb < n_w)
+      lattice_apply_body<T, P, 1, MODE, false, true>(args, vb, n_w, smem_raw + wave * cell_wave_lds<T, P>());
+  }
+  template <typename T, int P, int MODE>
+  __global__ void
+  __launch_bounds__(64 * CELL_WAVES, 6) cell_waves_kernel(const ApplyArgs<T, P> args)
+  {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    cell_waves_body<T, P, MODE>(args, blockIdx.x, gridDim.x, smem_raw);
+  }
+
   // persistent workgroups (lattice_apply_persistent_body); the grid is the number of RESIDENT workgroups (runtime.hip)
   template <typename T, int P, int B, int MODE, bool CONSTR = false>
   __global__ void
@@ -1897,7 +1950,7 @@ namespace mgamd
         ApplyArgs<T, P> a = args.a;
         a.g               = args.g_cells;
         a.stamps          = nullptr;
-        lattice_apply_body<T, P, 1, MODE>(a, blockIdx.x - args.n_wg_bricks, gridDim.x - args.n_wg_bricks, smem_raw);
+        cell_waves_body<T, P, MODE>(a, blockIdx.x - args.n_wg_bricks, gridDim.x - args.n_wg_bricks, smem_raw);
       }
   }
 

@@ -69,6 +69,12 @@ namespace mgamd
     static const bool on = getenv("MGAMD_NO_PERSISTENT") == nullptr;
     return on && !(P == 4 && std::is_same<T, float>::value);
   }
+  inline bool
+  use_cell_waves()
+  {
+    static const bool on = getenv("MGAMD_NO_CELL_WAVES") == nullptr;
+    return on;
+  }
   // two 4-wave workgroups with a 17^3 lattice pair each fit one CU; a multiple of 8 keeps a workgroup in its XCD's range
   inline int
   resident_workgroups(const Ctx *ctx)
@@ -137,6 +143,19 @@ namespace mgamd
     switch (B)
       {
         case 1:
+          if constexpr (P >= 2)
+            if (!diag && use_cell_waves())
+              { // single cells wave-scoped (kernels.hpp cell_waves_kernel); MGAMD_NO_CELL_WAVES=1: the workgroup-scoped kernel
+                using GW = Geo<P, 1, 64>;
+                if (a.g.n_slots == 0)
+                  return;
+                const uint32_t n_w  = (uint32_t)((a.g.n_slots + GW::SPW - 1) / GW::SPW);
+                const uint32_t grid = (n_w + CELL_WAVES - 1) / CELL_WAVES;
+                const size_t   lds  = CELL_WAVES * cell_wave_lds<T, P>();
+                hipLaunchKernelGGL((cell_waves_kernel<T, P, MODE>), grid, 64 * CELL_WAVES, lds, st, a);
+                HIP_CHECK(hipGetLastError());
+                return;
+              }
           launch_lattice<T, P, 1, MODE>(ctx, st, a, diag);
           return;
         case 2:
@@ -624,8 +643,12 @@ namespace mgamd
               sa.a           = a;
               sa.g_cells     = g1->view();
               sa.n_wg_bricks = (uint32_t)((g->n_slots + G2::SPW - 1) / G2::SPW);
-              const uint32_t n_wg_cells = (uint32_t)((g1->n_slots + G1::SPW - 1) / G1::SPW);
-              const size_t   lds = (std::max(2 * (size_t)G2::SPW * G2::N3, 2 * (size_t)G1::SPW * G1::N3) + 2 * P * P * P + std::max(G2::SPW, G1::SPW)) * sizeof(T);
+              // the cells wave-scoped: four wavefronts per workgroup with their own cells (kernels.hpp cell_waves_body)
+              using GW = Geo<P, 1, 64>;
+              const uint32_t n_w        = (uint32_t)((g1->n_slots + GW::SPW - 1) / GW::SPW);
+              const uint32_t n_wg_cells = (n_w + CELL_WAVES - 1) / CELL_WAVES;
+              const size_t   lds        = std::max((2 * (size_t)G2::SPW * G2::N3 + 2 * P * P * P + G2::SPW) * sizeof(T), CELL_WAVES * cell_wave_lds<T, P>());
+              (void)sizeof(G1);
               hipLaunchKernelGGL((lattice_apply_small_kernel<T, P, MODE>), sa.n_wg_bricks + n_wg_cells, 256, lds, st, sa);
               HIP_CHECK(hipGetLastError());
             }

@@ -16,6 +16,12 @@
 #pragma once
 #include "../../include/mgamd.h"
 
+#include <array>
+#include <chrono>
+#include <cstdio>
+#include <fstream>
+#include <thread>
+
 #include <functional>
 #include <memory>
 #include <stdexcept>
@@ -152,6 +158,42 @@ namespace mgamd
     return {seq.rbegin(), seq.rend()};
   }
 
+  // Domain decomposition of a level hierarchy, one rank per GPU (the reference partitions with p4est + RepartitioningPolicyTools,
+  // ref:multigrid_throughput.cc:2066-2175): Morton cut of a root level into n_ranks weighted chunks; finer levels inherit it,
+  // coarser levels are replicated.
+  class Partition
+  {
+  public:
+    Partition(const std::vector<std::shared_ptr<const Triangulation>> &triangulations, unsigned n_ranks, double hanging_weight = 2.0,
+              uint64_t min_root_cells = 0)
+      : triangulations(triangulations)
+    {
+      std::vector<const mgamd_tria *> t;
+      for (const auto &x : triangulations)
+        t.push_back(x->get());
+      mgamd_partition *p = nullptr;
+      check(mgamd_partition_create_ex(t.data(), (unsigned)t.size(), n_ranks, hanging_weight, min_root_cells, &p));
+      h.reset(p, mgamd_partition_destroy);
+      unsigned nr = 0;
+      check(mgamd_partition_info(h.get(), &root, &nr));
+    }
+    unsigned
+    root_level() const
+    {
+      return root;
+    }
+    mgamd_partition *
+    get() const
+    {
+      return h.get();
+    }
+    std::vector<std::shared_ptr<const Triangulation>> triangulations;
+
+  private:
+    std::shared_ptr<mgamd_partition> h;
+    unsigned                         root = 0;
+  };
+
   class DoFHandler
   {
   public:
@@ -165,6 +207,16 @@ namespace mgamd
         check(mgamd_dofs_create_level(tria->get(), (int)fe_degree, max_brick, &d));
       else
         check(mgamd_dofs_create(tria->get(), (int)fe_degree, max_brick, &d));
+      h.reset(d, mgamd_dofs_destroy);
+      check(mgamd_dofs_info(h.get(), &info));
+    }
+    // one rank's share of level `level` of a partitioned hierarchy (mgamd_dofs_create_local): its cells + halo plan on a
+    // distributed level, the whole level on a replicated one
+    DoFHandler(const Partition &partition, unsigned level, unsigned rank, unsigned fe_degree, int max_brick = -1)
+      : tria(partition.triangulations.at(level))
+    {
+      mgamd_dofs *d = nullptr;
+      check(mgamd_dofs_create_local(partition.get(), level, rank, (int)fe_degree, max_brick, &d));
       h.reset(d, mgamd_dofs_destroy);
       check(mgamd_dofs_info(h.get(), &info));
     }
@@ -212,6 +264,80 @@ namespace mgamd
 
   private:
     std::shared_ptr<mgamd_ctx> h;
+  };
+
+  // The communicator of a sharded run: RCCL over xGMI, one rank per GPU (what MPI_COMM_WORLD is to the reference,
+  // ref:multigrid_throughput.cc:2403-2442).  Every rank calls rccl() with the same 128-byte id; exchange_id_through_file is the
+  // host-side channel for launchers that only provide RANK / WORLD_SIZE (torchrun --no-python, a shell loop): rank 0 writes the
+  // id, the others wait for the file.
+  class Communicator
+  {
+  public:
+    Communicator() = default;
+    static std::array<char, 128>
+    exchange_id_through_file(const std::string &path, unsigned rank, double timeout_s = 120.0)
+    {
+      std::array<char, 128> id{};
+      if (rank == 0)
+        {
+          check(mgamd_comm_rccl_unique_id(id.data()));
+          const std::string tmp = path + ".tmp";
+          {
+            std::ofstream f(tmp, std::ios::binary | std::ios::trunc);
+            f.write(id.data(), 128);
+          }
+          if (std::rename(tmp.c_str(), path.c_str()) != 0)
+            throw std::runtime_error("cannot publish the RCCL id at " + path);
+          return id;
+        }
+      const auto t0 = std::chrono::steady_clock::now();
+      for (;;)
+        {
+          std::ifstream f(path, std::ios::binary);
+          if (f && f.read(id.data(), 128) && f.gcount() == 128)
+            return id;
+          if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
+            throw std::runtime_error("timed out waiting for the RCCL id at " + path);
+          std::this_thread::sleep_for(std::chrono::milliseconds(20));
+        }
+    }
+    static Communicator
+    rccl(const Context &ctx, unsigned n_ranks, unsigned rank, const std::array<char, 128> &id)
+    {
+      Communicator c;
+      mgamd_comm  *m = nullptr;
+      check(mgamd_comm_rccl_create(ctx.get(), n_ranks, rank, id.data(), &m));
+      c.h.reset(m, mgamd_comm_destroy);
+      c.n = n_ranks;
+      c.r = rank;
+      return c;
+    }
+    double
+    allreduce_sum(const Context &ctx, double v) const // Utilities::MPI::sum
+    {
+      double s = 0;
+      check(mgamd_comm_allreduce_sum(h.get(), ctx.get(), v, &s));
+      return s;
+    }
+    unsigned
+    n_ranks() const
+    {
+      return n;
+    }
+    unsigned
+    rank() const
+    {
+      return r;
+    }
+    mgamd_comm *
+    get() const
+    {
+      return h.get();
+    }
+
+  private:
+    std::shared_ptr<mgamd_comm> h;
+    unsigned                    n = 1, r = 0;
   };
 
   class Vector
@@ -300,6 +426,23 @@ namespace mgamd
       mgamd_level_op *o = nullptr;
       check(mgamd_level_op_create(ctx.get(), dof_handler.get(), number_type, &o));
       h.reset(o, mgamd_level_op_destroy);
+    }
+    // a level of a sharded hierarchy (DoFHandler(partition, level, rank, ...)): sums of shared DoFs are completed through `comm`
+    // (nullptr: replicated level)
+    void
+    reinit(const Context &ctx, const DoFHandler &dof_handler, int number_type, const Communicator *comm)
+    {
+      mgamd_level_op *o = nullptr;
+      check(mgamd_level_op_create_distributed(ctx.get(), dof_handler.get(), number_type, comm ? comm->get() : nullptr, &o));
+      h.reset(o, mgamd_level_op_destroy);
+    }
+    // DoFs this rank owns (sums to DoFHandler::n_dofs() over the ranks)
+    uint64_t
+    n_owned() const
+    {
+      uint64_t n = 0;
+      check(mgamd_level_op_n_owned(h.get(), &n));
+      return n;
     }
     uint64_t
     m() const

@@ -10,6 +10,8 @@
 #include "../csrc/mgamd.hpp"
 
 #include <algorithm>
+#include <cmath>
+#include <cstdlib>
 #include <chrono>
 #include <cstdio>
 #include <fstream>
@@ -239,8 +241,11 @@ resolve_policy_name(const RunParameters &params)
   return names[params.p];
 }
 
+// comm != nullptr: the run is SHARDED over comm->n_ranks() GPUs, one rank per GPU (the reference's MPI ranks,
+// ref:multigrid_throughput.cc:2403-2442): spatial domain decomposition of the level hierarchy (mgamd.hpp Partition), halo
+// exchange and coarse-level all-reduce over RCCL inside the library.  Implemented for Type "HMG-global" (BASELINE configs[3]).
 static void
-run(const Context &ctx, const RunParameters &params, ConvergenceTable &table)
+run(const Context &ctx, const RunParameters &params, ConvergenceTable &table, const Communicator *comm = nullptr)
 {
   const std::string policy = resolve_policy_name(params);
   {
@@ -320,6 +325,14 @@ run(const Context &ctx, const RunParameters &params, ConvergenceTable &table)
   else
     throw std::runtime_error("Type '" + params.type + "': not implemented");
   const bool local_smoothing = params.type == "HMG-local";
+  if (comm && params.type != "HMG-global")
+    throw std::runtime_error("sharded harness: Type '" + params.type + "' is not implemented (HMG-global is)");
+  // levels below ~4 M DoFs stay replicated
+  std::unique_ptr<Partition> partition;
+  if (comm)
+    partition = std::make_unique<Partition>(triangulations, comm->n_ranks(), 2.0,
+                                            (uint64_t)4000000 / ((uint64_t)params.fe_degree_fine * params.fe_degree_fine * params.fe_degree_fine));
+  auto distributed = [&](unsigned l) { return comm && comm->n_ranks() > 1 && l >= partition->root_level(); };
 
   const bool hp_local        = params.type == "HPMG-local";
   PreconditionChebyshev::AdditionalData sd;
@@ -360,6 +373,8 @@ run(const Context &ctx, const RunParameters &params, ConvergenceTable &table)
   for (unsigned l = 0; l < n_levels; ++l)
     if (hp_local && l == 0)
       dof_handlers.push_back(*ls_active); // the SAME DoFs as the local-smoothing cycle acts on
+    else if (comm)
+      dof_handlers.emplace_back(*partition, l, comm->rank(), degrees[l]);
     else
       dof_handlers.emplace_back(triangulations[l], degrees[l], -1, local_smoothing);
   std::unique_ptr<DoFHandler> active_dof_handler;
@@ -367,7 +382,10 @@ run(const Context &ctx, const RunParameters &params, ConvergenceTable &table)
     active_dof_handler = std::make_unique<DoFHandler>(tria, params.fe_degree_fine);
   const DoFHandler &fine_dof_handler = local_smoothing ? *active_dof_handler : dof_handlers.back();
   for (unsigned l = 0; l < n_levels; ++l)
-    operators[l].reinit(ctx, dof_handlers[l], level_number_type);
+    if (comm)
+      operators[l].reinit(ctx, dof_handlers[l], level_number_type, distributed(l) ? comm : nullptr);
+    else
+      operators[l].reinit(ctx, dof_handlers[l], level_number_type);
   for (unsigned l = 1; l < n_levels; ++l)
     transfers[l].reinit(operators[l], operators[l - 1]);
   for (unsigned l = 0; l < n_levels; ++l)
@@ -412,8 +430,13 @@ run(const Context &ctx, const RunParameters &params, ConvergenceTable &table)
   Operator op;
   if (level_number_type == MGAMD_F64 && !local_smoothing)
     op = operators.back();
+  else if (comm)
+    op.reinit(ctx, fine_dof_handler, MGAMD_F64, distributed(n_levels - 1) ? comm : nullptr);
   else
     op.reinit(ctx, fine_dof_handler, MGAMD_F64);
+  // DoFHandler::n_dofs() of the GLOBAL problem
+  const uint64_t n_dofs_global = (comm && distributed(n_levels - 1)) ? (uint64_t)std::llround(comm->allreduce_sum(ctx, (double)op.n_owned())) :
+                                                                       fine_dof_handler.n_dofs();
   Vector solution, rhs;
   op.initialize_dof_vector(solution);
   op.initialize_dof_vector(rhs);
@@ -426,8 +449,8 @@ run(const Context &ctx, const RunParameters &params, ConvergenceTable &table)
   table.add_value("degree", params.fe_degree_fine);
   table.add_value("n_ref_global", params.n_ref_global);
   table.add_value("n_ref_local", params.n_ref_local);
-  table.add_value("n_dofs", fine_dof_handler.n_dofs());
-  table.add_value("sub_comm_size", 1);
+  table.add_value("n_dofs", n_dofs_global);
+  table.add_value("sub_comm_size", comm ? comm->n_ranks() : 1);
 
   if (params.verbose)
     {
@@ -478,7 +501,7 @@ run(const Context &ctx, const RunParameters &params, ConvergenceTable &table)
   table.add_value("n_iterations", solver_control.last_step());
   table.add_value("time", time);
   table.add_value("time_cg", time_cg / its);
-  table.add_value("throughput", (double)rhs.size() * solver_control.last_step() / time, true);
+  table.add_value("throughput", (double)n_dofs_global * solver_control.last_step() / time, true);
   static const char *stage_cols[7] = {"time_pre", "time_residuum", "time_res", "time_cs", "time_pro", "time_edge_pro", "time_post"};
   double             t_v           = 0.0;
   for (unsigned j = 0; j < 7; ++j)
@@ -508,12 +531,12 @@ run(const Context &ctx, const RunParameters &params, ConvergenceTable &table)
           meshes.push_back(t);
       if (local_smoothing || meshes.size() == 1)
         meshes = create_geometric_coarsening_sequence(tria); // one mesh: its coarsening sequence (the level hierarchy)
-      for (const auto &stat : print_multigrid_statistics(meshes, 1))
+      for (const auto &stat : print_multigrid_statistics(meshes, comm ? comm->n_ranks() : 1))
         table.add_value(stat.first, stat.second, true);
     }
   // this project's additions (after the reference's columns): DoF/s per V-cycle = n_dofs / (sum of the nine stage columns)
   //  and the coarse solver that actually ran
-  table.add_value("dofs_per_s_per_vcycle", (double)rhs.size() / t_v, true);
+  table.add_value("dofs_per_s_per_vcycle", (double)n_dofs_global / t_v, true);
   table.add_value("coarse_solver", preconditioner.coarse_solver_used());
 
   if (params.verbose)
@@ -539,17 +562,46 @@ main(int argc, char **argv)
           printf("ERROR: No .json parameter files has been provided!\n");
           return 1;
         }
-      Context          ctx(0);
+      // One rank per GPU when launched with WORLD_SIZE / RANK / LOCAL_RANK in the environment (torchrun --no-python, mpirun -x,
+      // a shell loop): the RCCL id travels through a file that rank 0 writes (MGAMD_RCCL_ID_FILE, default derived from
+      // MASTER_PORT and the launcher's run id).  MGAMD_HARNESS_SHARDED=1 runs the sharded code path on one rank too.
+      auto env_uint = [](const char *name, unsigned dflt) {
+        const char *v = std::getenv(name);
+        return v ? (unsigned)std::strtoul(v, nullptr, 10) : dflt;
+      };
+      const unsigned world = env_uint("WORLD_SIZE", 1), rank = env_uint("RANK", 0), local_rank = env_uint("LOCAL_RANK", rank);
+      const bool     sharded = world > 1 || std::getenv("MGAMD_HARNESS_SHARDED") != nullptr;
+      Context          ctx((int)(sharded ? local_rank : 0));
       ConvergenceTable table;
+      Communicator     comm;
+      std::string      id_file;
+      if (sharded)
+        {
+          if (const char *f = std::getenv("MGAMD_RCCL_ID_FILE"))
+            id_file = f;
+          else
+            {
+              const char *port = std::getenv("MASTER_PORT"), *run = std::getenv("TORCHELASTIC_RUN_ID");
+              id_file = std::string("/tmp/mgamd_rccl_id_") + (port ? port : "0") + "_" + (run ? run : "default");
+            }
+          if (rank == 0)
+            std::remove(id_file.c_str()); // a stale id of an earlier job under the same name
+          comm = Communicator::rccl(ctx, world, rank, Communicator::exchange_id_through_file(id_file, rank));
+        }
       for (int i = 1; i < argc; i++)
         {
-          std::cout << std::string(argv[i]) << std::endl;
+          if (rank == 0)
+            std::cout << std::string(argv[i]) << std::endl;
           RunParameters params;
           params.parse(std::string(argv[i]));
-          run(ctx, params, table);
-          table.write_text(std::cout);
+          run(ctx, params, table, sharded ? &comm : nullptr);
+          if (rank == 0)
+            table.write_text(std::cout);
         }
-      table.write_text(std::cout);
+      if (rank == 0)
+        table.write_text(std::cout);
+      if (sharded && rank == 0)
+        std::remove(id_file.c_str());
     }
   catch (std::exception &exc)
     {
