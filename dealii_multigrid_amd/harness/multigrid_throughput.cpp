@@ -529,8 +529,17 @@ run(const Context &ctx, const RunParameters &params, ConvergenceTable &table, co
       for (const auto &t : triangulations)
         if (meshes.empty() || meshes.back().get() != t.get())
           meshes.push_back(t);
-      if (local_smoothing || meshes.size() == 1)
-        meshes = create_geometric_coarsening_sequence(tria); // one mesh: its coarsening sequence (the level hierarchy)
+      // local smoothing: the reference calls the single-triangulation overload (ref:multigrid_throughput.cc:1862-1872,
+      // ref:include/mg_tools.h:39-61,85,195), which counts ALL cells of each refinement level of the one mesh: `triangulations`
+      // holds exactly those level meshes here.  PMG (one mesh, several degrees): its coarsening sequence.
+      if (!local_smoothing && meshes.size() == 1)
+        meshes = create_geometric_coarsening_sequence(tria);
+      if (hp_local)
+        {
+          meshes.clear();
+          for (unsigned l = 0; l < tria->n_global_levels(); ++l)
+            meshes.push_back(tria->level_mesh(l));
+        }
       for (const auto &stat : print_multigrid_statistics(meshes, comm ? comm->n_ranks() : 1))
         table.add_value(stat.first, stat.second, true);
     }

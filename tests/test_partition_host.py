@@ -177,6 +177,7 @@ def test_halo_slots_come_first(mgamd, geo, L, p, n_ranks):
         info = d.info
         shared = np.zeros(d.n_dofs, bool)
         shared[info.n_interior + plan["sh_tail"]] = True
+        shared[info.n_interior + plan["pack_idx"]] = True  # everything the pack kernel reads while the interior slots run
         cg, cs = d.cell_slots()
         cd = d.cell_dofs()
         touches = {}  # (group, slot) -> touches a shared tail DoF
