@@ -36,7 +36,9 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 WORKLOADS = {
     # name: (geometry, NRefGlobal default, degree, Type, coarse solver, BASELINE.json config)
     "octant_p4": ("quadrant", 8, 4, "HMG-global", "amg", "configs[2]"),
-    "pmg_annulus": ("annulus", 8, 4, "PMG", "cg_with_chebyshev", "configs[4]"),
+    # (coarse solver "amg" with CoarseSolverNCycles 2: the reference's defaults, ref:scripts/default.json:11,14 -- here the library's
+    # own smoothed-aggregation AMG)
+    "pmg_annulus": ("annulus", 8, 4, "PMG", "amg", "configs[4]"),
 }
 
 
@@ -50,15 +52,16 @@ def algorithmic_bytes_per_vcycle(n_dofs_per_level, k=3, word=8):
 
 
 def run_workload(m, ctx, geometry, n_ref, degree, mg_type, coarse, steps, warmup, barrier, sync, profile, comm=None, details=False,
-                 number_type=None, diagnostics=False):
+                 number_type=None, diagnostics=False, coarse_cycles=1):
     t0 = time.time()
     number_type = m.F64 if number_type is None else number_type
     word = 8 if number_type == m.F64 else 4
     if comm is None:
-        h = m.Hierarchy(ctx, geometry, n_ref, degree, mg_type, smoother_degree=3, coarse_solver=coarse, number_type=number_type)
+        h = m.Hierarchy(ctx, geometry, n_ref, degree, mg_type, smoother_degree=3, coarse_solver=coarse, number_type=number_type,
+                        coarse_n_cycles=coarse_cycles)
     else:
         h = m.DistributedHierarchy(ctx, comm, geometry, n_ref, degree, mg_type=mg_type, smoother_degree=3, coarse_solver=coarse,
-                                   number_type=number_type)
+                                   number_type=number_type, coarse_n_cycles=coarse_cycles)
     # PreconditionMG::vmult acts on the OUTER vectors, which are double whatever MGNumberType is (ref:multigrid_throughput.cc:
     # 2430-2433 run<3, 1, double, MGNumber>): with float levels copy_to_mg / copy_from_mg cast
     if number_type == m.F64:
@@ -285,13 +288,18 @@ def main():
     ap.add_argument("--nref-uniform-p1", type=int, default=9, help="NRefGlobal of the uniform-mesh p=1 workload (135 M DoFs)")
     ap.add_argument("--cpu-nref", type=int, default=8, help="NRefGlobal of the CPU-baseline sample (default: the headline configuration)")
     ap.add_argument("--no-float", action="store_true", help="skip the MGNumberType float figure (also_float)")
-    ap.add_argument("--coarse", default=None, help="CoarseGridSolverType override (pmg_annulus: cg_with_chebyshev | cg | amg = geometric stand-in)")
+    ap.add_argument("--coarse", default=None, help="CoarseGridSolverType override (pmg_annulus: cg_with_chebyshev | cg | amg | cg_with_amg | "
+                    "gmg_vcycle = the geometric stand-in of rounds 1-2)")
+    ap.add_argument("--coarse-cycles", type=int, default=None, help="CoarseSolverNCycles (amg, cg_with_amg, gmg_vcycle); default 2 for "
+                    "pmg_annulus with amg (the reference's default.json), else 1")
     ap.add_argument("--mode", choices=["sharded", "replicas"], default="sharded", help="N > 1: domain decomposition (default) or replicas")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
     geometry, nref_default, degree, mg_type, coarse, cfg_name = WORKLOADS[args.workload]
     coarse = args.coarse or coarse
+    if args.coarse_cycles is None:
+        args.coarse_cycles = 2 if (args.workload == "pmg_annulus" and coarse == "amg") else 1
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.workload == "pmg_annulus" and world == 1:
@@ -328,7 +336,7 @@ def main():
             dist.broadcast(uid, 0)
             comm = m.Communicator.rccl(ctx, world, rank, bytes(uid.cpu().numpy().tobytes()))
         prim = run_workload(m, ctx, geometry, nref, degree, mg_type, coarse, args.steps, args.warmup, barrier, sync, profile=True, comm=comm,
-                            details=world == 1, diagnostics=True)
+                            details=world == 1, diagnostics=True, coarse_cycles=args.coarse_cycles)
     except Exception as e:  # noqa: BLE001
         # no fallback, no relabelled metric: the other ranks may be blocked inside a collective, so leave hard with a
         # non-zero status and let the launcher tear the job down
@@ -362,7 +370,8 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"3D {'octant (GeometryType quadrant)' if geometry == 'quadrant' else geometry} {mg_type} p={degree} FP64, "
-                        f"NRefGlobal={nref}, SmootherDegree=3, coarse solver {prim['coarse_solver']}, f=1, zero Dirichlet "
+                        f"NRefGlobal={nref}, SmootherDegree=3, coarse solver {prim['coarse_solver']}"
+                        + (f" x{args.coarse_cycles} cycles" if args.coarse_cycles > 1 else "") + ", f=1, zero Dirichlet "
                         f"(BASELINE.json {cfg_name})" + collapsed,
             "n_dofs": prim["n_dofs"], "n_cells": prim["n_cells"], "n_levels": prim["n_levels"], "level_dofs": prim["level_dofs"],
             "parallelism": "1 GPU" if world == 1 else (
@@ -463,7 +472,8 @@ def main():
                                      "float at p = 4), without fused transfers"}
     if world == 1 and args.workload == "pmg_annulus" and nref != 8 and not args.no_secondary:
         # the size BASELINE.json configs[4] shards over 8 GPUs, on one GPU for reference
-        sm = run_workload(m, ctx, geometry, 8, degree, mg_type, coarse, args.steps, args.warmup, lambda: None, sync, profile=False)
+        sm = run_workload(m, ctx, geometry, 8, degree, mg_type, coarse, args.steps, args.warmup, lambda: None, sync, profile=False,
+                          coarse_cycles=args.coarse_cycles)
         ts = sm["elapsed"] / args.steps
         out["also_sharded_size"] = {"metric": out["metric"], "value": sm["n_dofs"] / ts, "unit": "DoF/s", "n_gpus": 1, "ms_per_step": ts * 1e3,
                                     "n_dofs": sm["n_dofs"], "NRefGlobal": 8, "coarse_solver": sm["coarse_solver"],

@@ -224,6 +224,20 @@ class DoFs:
     def groups(self):
         return [(self.info.group_B[g], self.info.group_slots[g]) for g in range(self.info.n_groups)]
 
+    def matrix(self):
+        """the assembled level matrix (Operator::get_trilinos_system_matrix) as (row_ptr, col, val), CSR with sorted columns"""
+        nnz = C.c_uint64()
+        _chk(_lib.mgamd_dofs_matrix(self._h, C.byref(nnz), None, None, None))
+        ptr, col, val = np.zeros(self.n_dofs + 1, np.uint32), np.zeros(nnz.value, np.uint32), np.zeros(nnz.value)
+        _chk(_lib.mgamd_dofs_matrix(self._h, C.byref(nnz), _ptr(ptr), _ptr(col), _ptr(val)))
+        return ptr, col, val
+
+    def amg_setup_info(self):
+        """[(rows, nnz)] of the smoothed-aggregation hierarchy of the AMG coarse solver on this level, finest first"""
+        n, rows, nnz = C.c_uint32(), (C.c_uint32 * 32)(), (C.c_uint64 * 32)()
+        _chk(_lib.mgamd_dofs_amg_setup_info(self._h, C.byref(n), rows, nnz, 32))
+        return [(rows[l], nnz[l]) for l in range(n.value)]
+
     def cell_slots(self):
         grp, slot = np.zeros(self.info.n_cells, np.uint8), np.zeros(self.info.n_cells, np.uint32)
         _chk(_lib.mgamd_dofs_get_cell_slots(self._h, _ptr(grp), _ptr(slot)))
@@ -537,10 +551,9 @@ class PreconditionMG:
         self._h = C.c_void_p()
         if local_smoothing is not None:
             _chk(_lib.mgamd_mg_create_local_smoothing(ctx._h, n, L, T, S, local_smoothing._h, coarse_solver.encode(), C.byref(self._h)))
-        elif nested is None:
-            _chk(_lib.mgamd_mg_create(ctx._h, n, L, T, S, coarse_solver.encode(), C.byref(self._h)))
         else:
-            _chk(_lib.mgamd_mg_create_nested(ctx._h, n, L, T, S, coarse_solver.encode(), nested._h, n_cycles, C.byref(self._h)))
+            _chk(_lib.mgamd_mg_create_nested(ctx._h, n, L, T, S, coarse_solver.encode(), nested._h if nested is not None else None, n_cycles,
+                                             C.byref(self._h)))
         self._cb = None
 
     def set_collapse(self, enable: bool) -> int:
@@ -669,8 +682,9 @@ class Hierarchy:
         self.transfers = [None] + [MGTwoLevelTransfer(self.operators[l], self.operators[l - 1]) for l in range(1, len(self.dofs))]
         self.smoothers = [PreconditionChebyshev(op, smoother_degree, smoothing_range, eig_cg_n_iterations) for op in self.operators]
         self.coarse = None
-        if coarse_solver in AMG_COARSE_SOLVERS and self.dofs[0].n_dofs > 4096:
-            # the AMG coarse solvers on a large coarse level (PMG): geometric stand-in, V-cycles of the h-multigrid on level 0
+        if coarse_solver == "gmg_vcycle" and self.dofs[0].n_dofs > 4096:
+            # the geometric stand-in for the AMG coarse solvers on a large coarse level (PMG), now by explicit request only:
+            # V-cycles of the h-multigrid on level 0 ("amg", "cg_with_amg" run the library's smoothed-aggregation AMG)
             self.coarse = CoarseHierarchy(ctx, self.trias[0], self.dofs[0], self.operators[0], self.smoothers[0], smoother_degree,
                                           smoothing_range, eig_cg_n_iterations, number_type, max_brick)
         self.mg = PreconditionMG(ctx, self.operators, self.transfers, self.smoothers, coarse_solver,
@@ -750,8 +764,9 @@ class DistributedHierarchy:
         self.dofs, self.distributed, self.operators, self.transfers, self.smoothers = build(plan)
         self.coarse = None
         n0 = (int(round(comm.allreduce_sum(ctx, float(self.operators[0].n_owned())))) if self.distributed[0] else self.dofs[0].n_dofs)
-        if coarse_solver in AMG_COARSE_SOLVERS and n0 > 4096:
-            # geometric stand-in for the AMG coarse solvers: the h-multigrid on level 0's space (mgamd.h, "gmg_vcycle")
+        if (coarse_solver == "gmg_vcycle" or (coarse_solver in AMG_COARSE_SOLVERS and self.distributed[0])) and n0 > 4096:
+            # geometric stand-in for the AMG coarse solvers: the h-multigrid on level 0's space (mgamd.h, "gmg_vcycle"); the
+            # algebraic multigrid is built from ONE rank's assembled matrix, so a sharded coarse level takes the stand-in
             mi0, p0 = plan[0]
             cd, cdist, cops, ctr, csm = build([(l, p0) for l in range(mi0 + 1)], (self.dofs[0], self.operators[0], self.smoothers[0]))
             self.coarse = PreconditionMG(ctx, cops, ctr, csm, "amg")

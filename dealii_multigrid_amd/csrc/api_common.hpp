@@ -5,6 +5,7 @@
 #include "level_tables.hpp"
 #include "transfer_tables.hpp"
 #include "partition.hpp"
+#include "amg.hpp"
 
 #include <memory>
 #include <string>

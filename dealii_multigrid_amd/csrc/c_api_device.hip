@@ -539,7 +539,7 @@ mgamd_mg_create_nested(mgamd_ctx *ctx, unsigned n_levels, mgamd_level_op *const 
                        mgamd_cheb *const *smoothers, const char *coarse_solver, mgamd_mg *coarse_mg, unsigned n_cycles, mgamd_mg **out)
 {
   MGAMD_TRY
-  REQUIRE(ctx && levels && out && coarse_mg && n_levels > 0 && (n_levels == 1 || (transfers && smoothers)));
+  REQUIRE(ctx && levels && out && n_levels > 0 && (n_levels == 1 || (transfers && smoothers)));
   std::vector<LevelOperatorBase *> L(n_levels, nullptr);
   std::vector<Transfer2Base *>     Tr(n_levels, nullptr);
   std::vector<ChebyshevBase *>     Sm(n_levels, nullptr);
@@ -556,7 +556,7 @@ mgamd_mg_create_nested(mgamd_ctx *ctx, unsigned n_levels, mgamd_level_op *const 
   try
     {
       h->mg.reset(make_multigrid(ctx->ctx.get(), n_levels, L.data(), Tr.data(), Sm.data(), coarse_solver ? coarse_solver : "amg",
-                                 coarse_mg->mg.get(), n_cycles));
+                                 coarse_mg ? coarse_mg->mg.get() : nullptr, n_cycles));
     }
   catch (...)
     {

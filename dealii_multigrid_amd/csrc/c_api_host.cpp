@@ -58,6 +58,43 @@ mgamd_tria_create_from_leaves(uint64_t n_leaves, const uint8_t *level, const uin
 }
 
 int
+mgamd_dofs_matrix(const mgamd_dofs *d, uint64_t *nnz, uint32_t *row_ptr, uint32_t *col, double *val)
+{
+  MGAMD_TRY
+  if (!d || !nnz)
+    throw std::invalid_argument("null argument");
+  if (d->halo)
+    throw std::invalid_argument("mgamd_dofs_matrix: the level is distributed");
+  const CSR A = assemble_level_matrix(*d->tables);
+  *nnz        = A.nnz();
+  if (row_ptr)
+    std::copy(A.ptr.begin(), A.ptr.end(), row_ptr);
+  if (col)
+    std::copy(A.col.begin(), A.col.end(), col);
+  if (val)
+    std::copy(A.val.begin(), A.val.end(), val);
+  MGAMD_CATCH
+}
+
+int
+mgamd_dofs_amg_setup_info(const mgamd_dofs *d, uint32_t *n_levels, uint32_t *rows, uint64_t *nnz, uint32_t max_levels)
+{
+  MGAMD_TRY
+  if (!d || !n_levels)
+    throw std::invalid_argument("null argument");
+  const AmgHierarchyHost H = build_smoothed_aggregation(assemble_level_matrix(*d->tables));
+  *n_levels                = (uint32_t)H.levels.size();
+  for (uint32_t l = 0; l < H.levels.size() && l < max_levels; ++l)
+    {
+      if (rows)
+        rows[l] = H.levels[l].A.n_rows;
+      if (nnz)
+        nnz[l] = H.levels[l].A.nnz();
+    }
+  MGAMD_CATCH
+}
+
+int
 mgamd_tria_coarsen(const mgamd_tria *fine, mgamd_tria **out)
 {
   MGAMD_TRY

@@ -609,13 +609,13 @@ namespace mgamd
                                        n_cycles, &m));
           nested = coarse_mg->h; // keep the nested hierarchy's handle alive
         }
-      else
-        check(mgamd_mg_create(ctx.get(), n, L.data(), T.data(), S.data(), coarse_grid_solver_type.c_str(), &m));
+      else // (n_cycles = CoarseSolverNCycles of the algebraic coarse solvers "amg" / "cg_with_amg")
+        check(mgamd_mg_create_nested(ctx.get(), n, L.data(), T.data(), S.data(), coarse_grid_solver_type.c_str(), nullptr, n_cycles, &m));
       h.reset(m, mgamd_mg_destroy);
       slots.resize(9);
       n_levels = n;
     }
-    // the coarse solver that actually runs: "direct" | "cg" | "cg_with_chebyshev" | "gmg_vcycle" (see mgamd.h)
+    // the coarse solver that actually runs: "direct" | "cg" | "cg_with_chebyshev" | "amg" | "cg_with_amg" | "gmg_vcycle" (mgamd.h)
     std::string
     coarse_solver_used() const
     {

@@ -392,10 +392,11 @@ run(const Context &ctx, const RunParameters &params, ConvergenceTable &table, co
     smoothers[l].initialize(operators[l], sd);
 
   // coarse solver (library policy, include/mgamd.h): the Trilinos/PETSc AMG options are an exact solve on the one-cell coarse
-  // level of global coarsening; on a large coarse level (PMG, MinLevel) they are replaced by the geometric stand-in -- V-cycles
-  // of the h-multigrid on that level -- and the table says so in its `coarse_solver` column
+  // level of global coarsening and, on a large coarse level (PMG, MinLevel), the library's own smoothed-aggregation AMG.
+  // CoarseGridSolverType "gmg_vcycle" (this project's extension) selects the geometric stand-in of rounds 1-2 instead: V-cycles
+  // of the h-multigrid on that level.  The table says what ran in its `coarse_solver` column.
   const std::string coarse = hp_local ? std::string("gmg_vcycle") : params.mg_data.coarse_solver.type;
-  const bool amg_like      = coarse == "amg" || coarse == "cg_with_amg" || coarse == "amg_petsc";
+  const bool amg_like      = !hp_local && coarse == "gmg_vcycle";
   std::vector<DoFHandler>            c_dof_handlers;
   std::vector<Operator>              c_operators;
   std::vector<MGTwoLevelTransfer>    c_transfers;
@@ -419,9 +420,8 @@ run(const Context &ctx, const RunParameters &params, ConvergenceTable &table, co
         c_smoothers[l].initialize(c_operators[l], sd);
       c_smoothers[nc - 1] = smoothers[0];
       coarse_mg           = std::make_unique<PreconditionMG>(ctx, c_operators, c_transfers, c_smoothers, "amg");
-      std::cout << "note: CoarseGridSolverType '" << coarse << "' on the " << dof_handlers[0].n_dofs()
-                << "-DoF coarse level: Trilinos/PETSc are not available, using " << params.mg_data.coarse_solver.n_cycles
-                << " V-cycle(s) of the geometric multigrid on that level (gmg_vcycle)" << std::endl;
+      std::cout << "note: CoarseGridSolverType '" << coarse << "' on the " << dof_handlers[0].n_dofs() << "-DoF coarse level: "
+                << params.mg_data.coarse_solver.n_cycles << " V-cycle(s) of the geometric multigrid on that level" << std::endl;
     }
   PreconditionMG preconditioner(ctx, operators, transfers, smoothers, coarse, hp_local ? ls_mg.get() : coarse_mg.get(),
                                 hp_local ? 1u : params.mg_data.coarse_solver.n_cycles, active_dof_handler.get());

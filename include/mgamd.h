@@ -119,6 +119,15 @@ int mgamd_dofs_rhs_constant(const mgamd_dofs *d, double *out);
 int mgamd_dofs_rhs(const mgamd_dofs *d, int kind, double *out);
 int mgamd_dofs_distribute(const mgamd_dofs *d, int kind, double *x);
 
+/* Operator::get_trilinos_system_matrix / get_petsc_system_matrix (ref:include/operator.h:244-358: MatrixFreeTools::compute_matrix of
+ * the cell kernel with the constraints): the assembled level matrix C^T K C + identity on the constrained rows, CSR with sorted
+ * columns, in this library's DoF numbering.  Call with NULL arrays for *nnz; row_ptr has n_dofs + 1 entries.  It is what the AMG
+ * coarse solver is built on. */
+int mgamd_dofs_matrix(const mgamd_dofs *d, uint64_t *nnz, uint32_t *row_ptr, uint32_t *col, double *val);
+/* sizes of the smoothed-aggregation hierarchy the "amg" coarse solver builds on that matrix (mgamd_mg_create): rows and non-zeros
+ * per AMG level, finest first (arrays of max_levels entries, may be NULL) */
+int mgamd_dofs_amg_setup_info(const mgamd_dofs *d, uint32_t *n_levels, uint32_t *rows, uint64_t *nnz, uint32_t max_levels);
+
 /* Local smoothing (`HMG-local`, ref:multigrid_throughput.cc:1670-1873): level `level` of the refinement hierarchy = ALL
  * cells of that refinement level, active or not (DoFHandler::distribute_mg_dofs); its DoFs + zero Dirichlet boundary +
  * refinement-edge set (MGConstrainedDoFs / MGTools::extract_inner_interface_dofs, ref:include/operator.h:49-70,539-556);
@@ -254,17 +263,22 @@ int mgamd_transfer2_n_fused_bricks(const mgamd_transfer2 *t, uint64_t *n);
 /* Multigrid + PreconditionMG over MGTransferGlobalCoarsening (ref:multigrid_throughput.cc:1093-1133,
  * 1618-1621).  levels[0] is the coarsest; transfers[l] connects levels l-1 and l (transfers[0] unused,
  * may be NULL); smoothers[0] is only used by coarse solver "cg_with_chebyshev".
- * coarse_solver in {"direct","cg","cg_with_chebyshev"} (ref:multigrid_throughput.cc:911-944; the
- * Trilinos/PETSc AMG choices map to "direct"). */
+ * coarse_solver (CoarseGridSolverType, ref:multigrid_throughput.cc:909-1077):
+ *   "direct"             dense inverse (coarse levels up to 4096 DoFs)
+ *   "cg", "cg_with_chebyshev"   SolverCG to reltol 1e-4, unpreconditioned / with the level-0 Chebyshev smoother (:911-944)
+ *   "amg", "cg_with_amg", "amg_petsc"   the reference applies Trilinos ML / BoomerAMG to Operator::get_trilinos_system_matrix
+ *                        (:945-1077).  Here: on a coarse level of <= 4096 DoFs (global coarsening ends on one cell) an exact solve
+ *                        ("direct"); on a larger one (PMG: the p = 1 space on the finest mesh) the library's OWN
+ *                        smoothed-aggregation AMG on the assembled level matrix (mgamd_dofs_matrix; Chebyshev(2) smoothing, dense
+ *                        coarsest solve), applied CoarseSolverNCycles times as the coarse solver ("amg") or as the preconditioner
+ *                        of the coarse CG ("cg_with_amg").  Same role and inputs as ML, not the same aggregates: its iteration
+ *                        counts cannot be parity-checked against ML.
+ * mgamd_mg_create_nested additionally takes n_cycles (CoarseSolverNCycles) and, optionally, `coarse_mg`: a geometric multigrid
+ * whose finest level IS levels[0]; if given, it takes the AMG's place ("gmg_vcycle": x = V(b), x += V(b - A x) ...; the only choice
+ * on a sharded coarse level).  mgamd_mg_coarse_solver_used returns what runs: "direct" | "cg" | "cg_with_chebyshev" | "amg" |
+ * "cg_with_amg" | "gmg_vcycle". */
 int mgamd_mg_create(mgamd_ctx *ctx, unsigned n_levels, mgamd_level_op *const *levels, mgamd_transfer2 *const *transfers,
                     mgamd_cheb *const *smoothers, const char *coarse_solver, mgamd_mg **out);
-/* The reference's AMG coarse solvers ("amg": one ML V-cycle applied CoarseSolverNCycles times, "cg_with_amg", "amg_petsc":
- * ref:multigrid_throughput.cc:945-1077) need Trilinos/PETSc.  Policy of this library (one place, never silent):
- *   - coarse level of <= 4096 DoFs (global coarsening ends on one cell): an exact solve, "direct";
- *   - larger coarse levels (PMG: the p = 1 space on the finest mesh): mgamd_mg_create refuses; mgamd_mg_create_nested takes
- *     the geometric stand-in: `coarse_mg`, an h-multigrid whose finest level IS levels[0], applied n_cycles times
- *     (x = V(b), x += V(b - A x) ...), reported as "gmg_vcycle".
- * mgamd_mg_coarse_solver_used returns what runs: "direct" | "cg" | "cg_with_chebyshev" | "gmg_vcycle". */
 int mgamd_mg_create_nested(mgamd_ctx *ctx, unsigned n_levels, mgamd_level_op *const *levels, mgamd_transfer2 *const *transfers,
                            mgamd_cheb *const *smoothers, const char *coarse_solver, mgamd_mg *coarse_mg, unsigned n_cycles,
                            mgamd_mg **out);

@@ -88,20 +88,25 @@ def test_double_levels_match_oracle_iteration_counts(oracle, tmp_path):
         assert r["coarse_solver"] == "direct"
 
 
-def test_amg_on_a_large_coarse_level_runs_the_geometric_stand_in(oracle, tmp_path):
-    """PMG with the reference's default CoarseGridSolverType "amg": the p = 1 coarse level of annulus L = 6 has 9,763 DoFs.
-    The harness says what it does (note + coarse_solver column) and, for one AMG cycle, the preconditioner is the HPMG
-    V-cycle (the h-multigrid below the p-levels): iteration counts equal to the oracle's HPMG hierarchy."""
+def test_amg_on_a_large_coarse_level(oracle, tmp_path):
+    """PMG with the reference's default CoarseGridSolverType "amg": the p = 1 coarse level of annulus L = 6 has 9,763 DoFs: the
+    library's smoothed-aggregation AMG runs (coarse_solver column "amg").  With CoarseGridSolverType "gmg_vcycle" (this project's
+    extension: the geometric stand-in of rounds 1-2) and one cycle the preconditioner is the HPMG V-cycle: iteration counts
+    equal to the oracle's HPMG hierarchy; the algebraic solver needs at most one iteration more."""
     base = json.load(open(os.path.join(GOLDEN, "input_0003.json")))
-    cfg = dict(base, Type="PMG", GeometryType="annulus", NRefGlobal=6, Degree=2, MGNumberType="double", CoarseSolverNCycles=1)
-    f = str(tmp_path / "pmg.json")
-    json.dump(cfg, open(f, "w"))
-    rc, out, err = run_harness(f)
-    assert rc == 0, err
-    header, rows = final_table(out)
-    assert rows[0]["coarse_solver"] == "gmg_vcycle" and "gmg_vcycle" in out and int(rows[0]["n_dofs"]) == 71509
-    assert int(rows[0]["n_levels"]) == 2
-    assert int(rows[0]["n_iterations"]) == oracle_iterations(oracle, "annulus", 6, 2, "HPMG")
+    its = {}
+    for coarse in ("amg", "gmg_vcycle"):
+        cfg = dict(base, Type="PMG", GeometryType="annulus", NRefGlobal=6, Degree=2, MGNumberType="double", CoarseSolverNCycles=1,
+                   CoarseGridSolverType=coarse)
+        f = str(tmp_path / f"pmg_{coarse}.json")
+        json.dump(cfg, open(f, "w"))
+        rc, out, err = run_harness(f)
+        assert rc == 0, err
+        header, rows = final_table(out)
+        assert rows[0]["coarse_solver"] == coarse and int(rows[0]["n_dofs"]) == 71509 and int(rows[0]["n_levels"]) == 2
+        its[coarse] = int(rows[0]["n_iterations"])
+    assert its["gmg_vcycle"] == oracle_iterations(oracle, "annulus", 6, 2, "HPMG")
+    assert its["amg"] <= its["gmg_vcycle"] + 1
 
 
 def test_local_smoothing_inputs(tmp_path):
