@@ -1,7 +1,9 @@
 """The 17^3-lattice kernels exist in two forms (persistent workgroups with a software pipeline = default; one workgroup per
 brick = MGAMD_NO_PERSISTENT=1), and tail_kernel reads D^-1 either through one-byte codes (default) or from the vector
-(MGAMD_NO_DINV_CODES=1).  Every other GPU test runs the defaults; here the alternatives are checked against them on meshes
-with several 17^3 bricks (the switches are read when the library is loaded, hence child processes)."""
+(MGAMD_NO_DINV_CODES=1).  Round 3 added: level transfers fused into the brick kernel (default) or as separate kernels
+(MGAMD_NO_FUSED_TRANSFER=1) and wave-scoped single cells (default) or workgroup-scoped ones (MGAMD_NO_CELL_WAVES=1).  Every other
+GPU test runs the defaults; here the alternatives are checked against them on meshes with several 17^3 bricks (the switches are
+read when the library is loaded, hence child processes)."""
 import os
 import subprocess
 import sys
@@ -27,6 +29,18 @@ def test_alternative_kernel_paths_agree(tmp_path, geo, L, p):
     ref = run(geo, L, p, str(tmp_path / "default.npz"), {})
     assert any(g[1] > 1 and p * g[0] + 1 == 17 for g in ref["groups"]), "the case must contain several 17^3-lattice bricks"
     alt = run(geo, L, p, str(tmp_path / "alt.npz"), {"MGAMD_NO_PERSISTENT": "1", "MGAMD_NO_DINV_CODES": "1"})
+    for key in ("ax", "step", "vcycle"):
+        a, b = ref[key], alt[key]
+        assert np.linalg.norm(a - b) <= 1e-12 * np.linalg.norm(a), key
+
+
+@pytest.mark.parametrize("geo,L,p", [("quadrant", 6, 4), ("annulus", 6, 2), ("quadrant", 5, 3)])
+def test_round3_kernel_paths_agree(tmp_path, geo, L, p):
+    """hanging-node meshes with many single cells (and, at p = 4, 17^3 bricks with fused transfers): separate transfer kernels
+    and workgroup-scoped cell kernels give the defaults' results to rounding"""
+    ref = run(geo, L, p, str(tmp_path / "default.npz"), {})
+    assert any(g[0] == 1 and g[1] > 8 for g in ref["groups"]), "the case must contain single-cell slots"
+    alt = run(geo, L, p, str(tmp_path / "alt.npz"), {"MGAMD_NO_FUSED_TRANSFER": "1", "MGAMD_NO_CELL_WAVES": "1"})
     for key in ("ax", "step", "vcycle"):
         a, b = ref[key], alt[key]
         assert np.linalg.norm(a - b) <= 1e-12 * np.linalg.norm(a), key
