@@ -109,6 +109,28 @@ namespace mgamd
               flags[t] = fl;
           }
       };
+      // fused transfers: DoFs that some cell reaches through a hanging-node constraint.  The constrained cell's patch does not
+      // claim them (weight 0 on constrained nodes), so the "un-fused patches claim first" rule below would leave them to a
+      // fused brick although a slot outside the fused set adds to their residual: a brick that touches one stays un-fused
+      // (tools/fuse_plan_check.cpp checks the invariant on the host; annulus L = 8, p = 4 has 24 such bricks)
+      std::vector<bool> reached_through_constraint;
+      if (use_bricks && fuse_group >= 0 && &tf != &tc && pf == pc)
+        {
+          reached_through_constraint.assign(fine.n_dofs, false);
+          const int n = pf + 1;
+          for (size_t ci = 0; ci < tf.cells.size(); ++ci)
+            if ((tf.masks[ci] >> MASK_FACE_SHIFT) && fine.cell_is_local(ci))
+              for (int c = 0; c < n; ++c)
+                for (int b = 0; b < n; ++b)
+                  for (int a = 0; a < n; ++a)
+                    {
+                      const int      l[3] = {a, b, c};
+                      bool           constrained = false;
+                      const uint32_t idx = fine.cell_node_index(ci, l, &constrained);
+                      if (constrained && idx != INVALID_DOF)
+                        reached_through_constraint[idx] = true;
+                    }
+        }
       if (use_bricks && &tf != &tc && pf == pc)
         for (size_t gi = 0; gi < fine.groups.size(); ++gi)
           {
@@ -147,7 +169,13 @@ namespace mgamd
                       }
                 if (!ok)
                   continue;
-                const int f = (bg.fused && s >= fg.n_halo_slots) ? 1 : 0;
+                int f = (bg.fused && s >= fg.n_halo_slots) ? 1 : 0;
+                for (int t = 0; f && t < fg.n_shell; ++t)
+                  {
+                    const uint32_t idx = fg.shell_idx[s * fg.n_shell + t];
+                    if (idx != INVALID_DOF && reached_through_constraint[idx])
+                      f = 0;
+                  }
                 slots[f].push_back((uint32_t)s);
                 for (int32_t par : parents)
                   covered[par] = true;

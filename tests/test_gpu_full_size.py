@@ -22,13 +22,17 @@ def _random_free(mgamd, ctx, n, first_constrained, seed):
     return mgamd.Vector(ctx, n).from_host(x)
 
 
-@pytest.mark.parametrize("geo,L,p,expected_iterations", [("quadrant", 8, 4, 3), ("hypercube", 9, 1, 4)])
-def test_bench_workload_at_full_size(mgamd, ctx, geo, L, p, expected_iterations):
+# the annulus (configs[4]'s mesh, here with h-multigrid at p = 4) is the case whose 17-point bricks border constrained cells: bricks
+# that a hanging-node constraint reaches must stay out of the fused transfers (transfer_tables.hpp; an ownership plan without that
+# rule lost their residual contributions at NRefGlobal 8 only -- CG then stalls)
+@pytest.mark.parametrize("geo,L,p,expected_iterations,min_dofs,min_fused",
+                         [("quadrant", 8, 4, 3, 130_000_000, 20000), ("hypercube", 9, 1, 4, 130_000_000, 20000), ("annulus", 8, 4, 4, 18_000_000, 300)])
+def test_bench_workload_at_full_size(mgamd, ctx, geo, L, p, expected_iterations, min_dofs, min_fused):
     h = mgamd.Hierarchy(ctx, geo, L, p, "HMG-global", coarse_solver="amg")
     info = h.dofs[-1].info
     n, first_c = h.n_dofs, info.n_interior + info.n_tail
-    assert n > 130_000_000
-    assert sum(t.n_fused_bricks() for t in h.transfers[1:]) > 20000  # the fused-transfer kernels are what runs
+    assert n > min_dofs
+    assert sum(t.n_fused_bricks() for t in h.transfers[1:]) > min_fused  # the fused-transfer kernels are what runs
     u, v = _random_free(mgamd, ctx, n, first_c, 1), _random_free(mgamd, ctx, n, first_c, 2)
     zu, zv, zw, w = (mgamd.Vector(ctx, n) for _ in range(4))
     h.mg.vmult(zu, u)
