@@ -267,6 +267,7 @@ namespace mgamd
         if (any_hanging)
           brick_constraint_passes<T, P, B, BLOCK>(bufA, args.m, tid, nslots, args.g.fmask + slot0, false, G::ROUNDS == 1 ? &fm_line : nullptr);
       }
+    MGAMD_STAMP(5)
 
     if (!MGAMD_ABLATED(1))
       {
@@ -275,6 +276,7 @@ namespace mgamd
         else
           lattice_sweeps<T, P, B, BLOCK, NoHook, false, false, WAVE>(bufA, bufB, args.m, tid, nslots, args.g.h + slot0);
       }
+    MGAMD_STAMP(6)
 
     if (B == 1 && any_hanging)
       hanging_passes<T, P, WAVE>(bufA, args.m, sl, u, v, act, mask, true);

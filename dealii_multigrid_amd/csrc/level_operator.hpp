@@ -365,6 +365,8 @@ namespace mgamd
         }
       if (const char *e = getenv("MGAMD_ABLATE"))
         ablate = (uint32_t)atoi(e);
+      if (const char *e = getenv("MGAMD_STAMP_B")) // debug: stamp the group of this brick size instead of the largest one
+        prof_B = atoi(e);
       merge_small = getenv("MGAMD_NO_MERGE_SMALL") == nullptr;
       halo_overlap = getenv("MGAMD_NO_HALO_OVERLAP") == nullptr;
       if (const char *e = getenv("MGAMD_STAMPS"))

@@ -33,6 +33,10 @@ print(f"  per-WG total   : median {np.median(dur):6.2f} us  p10 {np.percentile(d
 for k, name in enumerate(["gather (issue+wait+LDS)", "sweeps (+epilogue operand issue)", "interior epilogue", "shell atomics + drain"]):
     ph = (st[:, k + 1] - st[:, k]) * tick
     print(f"  {name:34s}: median {np.median(ph):6.2f} us  p10 {np.percentile(ph,10):6.2f}  p90 {np.percentile(ph,90):6.2f}")
+if (st[:, 5] > 0).all() and (st[:, 6] > 0).all():  # the one-shot body also stamps the constraint passes
+    for name, a, b in [("  of which: interpolation passes", 1, 5), ("            sweeps", 5, 6), ("            transposed passes", 6, 2)]:
+        ph = (st[:, b] - st[:, a]) * tick
+        print(f"  {name:34s}: median {np.median(ph):6.2f} us  p10 {np.percentile(ph,10):6.2f}  p90 {np.percentile(ph,90):6.2f}")
 starts = np.sort(st[:, 0] - t0) * tick
 print("  WG start times (us) quantiles:", [round(float(np.percentile(starts, q)), 1) for q in (0, 5, 25, 50, 75, 95, 100)])
 # concurrency: average number of WGs alive
