@@ -467,9 +467,8 @@ def main():
                              "value": flt["n_dofs"] / tf, "unit": "DoF/s", "n_gpus": 1, "ms_per_step": tf * 1e3, "dtype": "f32",
                              "n_dofs": flt["n_dofs"], "NRefGlobal": nref, "bytes_model": "SURVEY 8(d) with 4-byte words",
                              "vcycle_frac_of_hbm_peak": flt["bytes_per_vcycle"] / tf / 1e9 / HBM_PEAK_GBS,
-                             "fused_transfer_bricks": flt["fused_transfer_bricks"],
-                             "note": "p = 4 float runs the one-workgroup-per-brick kernels (the persistent Chebyshev instantiation spills in "
-                                     "float at p = 4), without fused transfers"}
+                             "fused_transfer_bricks": flt["fused_transfer_bricks"], "cg_iterations_reltol_1e-4": flt["cg_iterations"],
+                             "note": "same kernels as FP64 (persistent 17^3 bricks, fused transfers) on float level vectors with float constants"}
     if world == 1 and args.workload == "pmg_annulus" and nref != 8 and not args.no_secondary:
         # the size BASELINE.json configs[4] shards over 8 GPUs, on one GPU for reference
         sm = run_workload(m, ctx, geometry, 8, degree, mg_type, coarse, args.steps, args.warmup, lambda: None, sync, profile=False,

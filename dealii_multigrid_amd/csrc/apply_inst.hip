@@ -17,12 +17,8 @@ namespace mgamd
   MGAMD_INST(MODE_CHEB)
   MGAMD_INST(MODE_CHEB_FIRST)
   MGAMD_INST(MODE_CHEB_SECOND)
-  // the passes with fused level transfers: degrees with a persistent 17-point lattice kernel (not float at p = 4, see
-  // use_persistent in level_operator.hpp)
-#define MGAMD_IS_float 1
-#define MGAMD_CAT_(a, b) a##b
-#define MGAMD_CAT(a, b) MGAMD_CAT_(a, b)
-#if (MGAMD_INST_P == 1 || MGAMD_INST_P == 2 || MGAMD_INST_P == 4) && !(MGAMD_INST_P == 4 && MGAMD_CAT(MGAMD_IS_, MGAMD_INST_T) + 0 == 1)
+  // the passes with fused level transfers: degrees with a persistent 17-point lattice kernel
+#if MGAMD_INST_P == 1 || MGAMD_INST_P == 2 || MGAMD_INST_P == 4
   MGAMD_INST(MODE_RESIDUAL_RESTRICT)
   MGAMD_INST(MODE_CHEB_PROLONGATE)
 #endif

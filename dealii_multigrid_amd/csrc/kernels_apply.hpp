@@ -835,9 +835,17 @@ namespace mgamd
   }
 
   // persistent workgroups (lattice_apply_persistent_body); the grid is the number of RESIDENT workgroups (runtime.hip)
+  // workgroups per CU: two f64 lattice pairs fill the LDS; three f32 pairs would fit, and at p = 4 the float kernels can be held
+  // to 168 VGPRs, but measured no gain (octant p = 4 float 7.07 vs 6.73 ms per V-cycle, boxes 4 % apart): two everywhere
+  template <typename T, int P>
+  constexpr int
+  persistent_wgs_per_cu()
+  {
+    return 2;
+  }
   template <typename T, int P, int B, int MODE, bool CONSTR = false>
   __global__ void
-  __launch_bounds__((Geo<P, B>::ABLOCK), 2) lattice_apply_persistent_kernel(const ApplyArgs<T, P> args)
+  __launch_bounds__((Geo<P, B>::ABLOCK), (persistent_wgs_per_cu<T, P>())) lattice_apply_persistent_kernel(const ApplyArgs<T, P> args)
   {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     lattice_apply_persistent_body<T, P, B, MODE, CONSTR>(args, blockIdx.x, gridDim.x, smem_raw);
@@ -950,7 +958,7 @@ namespace mgamd
   struct ClusterArgs
   {
     CellClusterDev c;
-    Mats<1>        m;
+    Mats<1, T>     m;
     const T       *src;
     T             *tail_acc;
     uint32_t       n_interior;
@@ -963,7 +971,7 @@ namespace mgamd
 
   template <typename T, bool TRANSPOSE>
   __device__ __forceinline__ void
-  hanging_in_registers_p1(T (&x)[8], const uint32_t mask, const Mats<1> &m)
+  hanging_in_registers_p1(T (&x)[8], const uint32_t mask, const Mats<1, T> &m)
   {
     const int  cx = mask & 1, cy = (mask >> 1) & 1, cz = (mask >> 2) & 1;
     const bool fx = (mask >> 3) & 1, fy = (mask >> 4) & 1, fz = (mask >> 5) & 1;
@@ -1002,7 +1010,7 @@ namespace mgamd
               const int i1 = i0 + (d == 0 ? 1 : (d == 1 ? 2 : 4));
               if (on)
                 {
-                  const double *w  = c ? m.I1 : m.I0;
+                  const T *w       = c ? m.I1 : m.I0;
                   const T       a0 = x[i0], a1 = x[i1];
                   if (TRANSPOSE)
                     {

@@ -32,17 +32,19 @@ namespace mgamd
     return k * q + (k < r ? k : r) + (b >> 3);
   }
 
-  template <int P>
+  // S: the number type of the kernel that takes them as arguments (round 3: float kernels converted the double constants at every
+  // use, which cost them the registers of the double kernels)
+  template <int P, typename S = double>
   struct Mats
   {
-    double M[(P + 1) * (P + 1)];
-    double K[(P + 1) * (P + 1)];
-    double I0[(P + 1) * (P + 1)];
-    double I1[(P + 1) * (P + 1)];
+    S M[(P + 1) * (P + 1)];
+    S K[(P + 1) * (P + 1)];
+    S I0[(P + 1) * (P + 1)];
+    S I1[(P + 1) * (P + 1)];
     // even-odd decomposition of the centrosymmetric M and K (GLL nodes are symmetric): A x = Ae xe + Ao xo with
     // xe_j = x_j + x_{P-j}, xo_j = x_j - x_{P-j};  Ae_ij = (A_ij + A_i,P-j)/2 (middle column: A_i,mid), Ao_ij = (A_ij - A_i,P-j)/2
     static constexpr int NH = (P + 2) / 2, NO = (P + 1) / 2;
-    double               Me[NH * NH], Mo[NO * NO], Ke[NH * NH], Ko[NO * NO];
+    S                    Me[NH * NH], Mo[NO * NO], Ke[NH * NH], Ko[NO * NO];
   };
 
   // Bricks that may carry whole-face / whole-edge hanging-node constraints (see lattice_apply_body): families (B = 2) share
@@ -166,7 +168,7 @@ namespace mgamd
   // out[0..N) = (1D matrix assembled from B copies of the (P+1)^2 cell matrix Mc) * in
   template <typename T, int P, int B>
   __device__ __forceinline__ void
-  line_mult(const double *__restrict__ Mc, const T (&in)[P * B + 1], T (&out)[P * B + 1])
+  line_mult(const T *__restrict__ Mc, const T (&in)[P * B + 1], T (&out)[P * B + 1])
   {
 #pragma unroll
     for (int i = 0; i < P * B + 1; ++i)
@@ -202,7 +204,7 @@ namespace mgamd
     // this = Ae * xe, Ao * xo (accumulating if ACC)
     template <bool ACC>
     __device__ __forceinline__ void
-    apply(const double *__restrict__ Ae, const double *__restrict__ Ao, const EvenOdd &x)
+    apply(const T *__restrict__ Ae, const T *__restrict__ Ao, const EvenOdd &x)
     {
 #pragma unroll
       for (int i = 0; i < NH; ++i)
@@ -241,7 +243,7 @@ namespace mgamd
   // outM = M a, outK = K a
   template <typename T, int P, int B>
   __device__ __forceinline__ void
-  line_MK(const Mats<P> &m, const T (&a)[P * B + 1], T (&outM)[P * B + 1], T (&outK)[P * B + 1])
+  line_MK(const Mats<P, T> &m, const T (&a)[P * B + 1], T (&outM)[P * B + 1], T (&outK)[P * B + 1])
   {
     if constexpr (P < 4) // no saving below 5x5 blocks
       {
@@ -266,7 +268,7 @@ namespace mgamd
   // outM = M a, outS = K a + M b
   template <typename T, int P, int B>
   __device__ __forceinline__ void
-  line_M_KM(const Mats<P> &m, const T (&a)[P * B + 1], const T (&b)[P * B + 1], T (&outM)[P * B + 1], T (&outS)[P * B + 1])
+  line_M_KM(const Mats<P, T> &m, const T (&a)[P * B + 1], const T (&b)[P * B + 1], T (&outM)[P * B + 1], T (&outS)[P * B + 1])
   {
     if constexpr (P < 4)
       {
@@ -298,7 +300,7 @@ namespace mgamd
   // outS = K a + M b
   template <typename T, int P, int B>
   __device__ __forceinline__ void
-  line_KM(const Mats<P> &m, const T (&a)[P * B + 1], const T (&b)[P * B + 1], T (&outS)[P * B + 1])
+  line_KM(const Mats<P, T> &m, const T (&a)[P * B + 1], const T (&b)[P * B + 1], T (&outS)[P * B + 1])
   {
     if constexpr (P < 4)
       {
@@ -334,7 +336,7 @@ namespace mgamd
   // more doubles in registers: measured -4 % on the 2-4-word passes, but the 5-word Chebyshev pass then spills)
   template <typename T, int P, int B, int KIND, bool PREFETCH>
   __device__ __forceinline__ void
-  line_stream(const Mats<P> &m, T *__restrict__ A, T *__restrict__ Bb, const int stride, const T scale)
+  line_stream(const Mats<P, T> &m, T *__restrict__ A, T *__restrict__ Bb, const int stride, const T scale)
   {
     constexpr int n = P + 1;
     T             a[n], b[n], an[n], bn[n], c1 = T(0), c2 = T(0);
@@ -478,7 +480,7 @@ namespace mgamd
   // KIND 0: o1 = M a, o2 = K a;  1: o1 = M a, o2 = K a + M b;  2: o2 = K a + M b.   a, b: [P left nodes | 5 own nodes]
   template <typename T, int P, int KIND>
   __device__ __forceinline__ void
-  seg_products(const Mats<P> &m, const T (&a)[P + 5], const T (&b)[P + 5], const bool has_left, T (&o1)[5], T (&o2)[5])
+  seg_products(const Mats<P, T> &m, const T (&a)[P + 5], const T (&b)[P + 5], const bool has_left, T (&o1)[5], T (&o2)[5])
   {
     static_assert(4 % P == 0, "segments of 5 nodes need P in {1, 2, 4}");
     constexpr int CPS = 4 / P; // cells per segment
@@ -534,7 +536,7 @@ namespace mgamd
   // persistent kernel requests its epilogue operands there)
   template <typename T, int P, int B, int BLOCK, typename Hook = NoHook, bool STREAMED = false, bool PREFETCH = false, bool WAVE = false>
   __device__ __forceinline__ void
-  lattice_sweeps(T *__restrict__ bufA, T *__restrict__ bufB, const Mats<P> &m, int tid, int nslots, const double *__restrict__ hslot,
+  lattice_sweeps(T *__restrict__ bufA, T *__restrict__ bufB, const Mats<P, T> &m, int tid, int nslots, const double *__restrict__ hslot,
                  const Hook &before_x = Hook(), const bool h_is_mine = false) // h_is_mine: hslot[0] is the h of THIS thread's line
   {
     using G              = Geo<P, B, WAVE ? 64 : 256>;
@@ -699,7 +701,7 @@ namespace mgamd
   // faces/edges do work.  Ends with a barrier.
   template <typename T, int P, bool WAVE = false>
   __device__ __forceinline__ void
-  hanging_passes(T *__restrict__ buf, const Mats<P> &m, int sl, int u, int v, bool act, uint32_t mask, bool transpose)
+  hanging_passes(T *__restrict__ buf, const Mats<P, T> &m, int sl, int u, int v, bool act, uint32_t mask, bool transpose)
   {
     constexpr int N  = P + 1;
     constexpr int N3 = N * N * N;
@@ -771,7 +773,7 @@ namespace mgamd
   // One thread per line (sl, u, v) as in the sweeps, in rounds of BLOCK lines.  Ends with a barrier.
   template <typename T, int P, int B, int BLOCK>
   __device__ __forceinline__ void
-  brick_constraint_passes(T *__restrict__ buf, const Mats<P> &m, int tid, int nslots, const uint32_t *__restrict__ fmask, bool transpose,
+  brick_constraint_passes(T *__restrict__ buf, const Mats<P, T> &m, int tid, int nslots, const uint32_t *__restrict__ fmask, bool transpose,
                           const uint32_t *fm_mine = nullptr) // fm_mine: the mask of this thread's line(s), already in a register
   {
     using G               = Geo<P, B>;
@@ -871,7 +873,7 @@ namespace mgamd
   // fine line (P*BC*2+1) from coarse line (P*BC+1), cell by cell
   template <typename T, int P, int BC>
   __device__ __forceinline__ void
-  line_embed(const double *__restrict__ E, const T (&in)[P * BC + 1], T (&out)[2 * P * BC + 1])
+  line_embed(const T *__restrict__ E, const T (&in)[P * BC + 1], T (&out)[2 * P * BC + 1])
   {
 #pragma unroll
     for (int c = 0; c < BC; ++c)
@@ -888,7 +890,7 @@ namespace mgamd
   // transpose: coarse line += E^T fine line; fine nodes shared by two coarse cells are counted once
   template <typename T, int P, int BC>
   __device__ __forceinline__ void
-  line_embed_T(const double *__restrict__ E, const T (&in)[2 * P * BC + 1], T (&out)[P * BC + 1])
+  line_embed_T(const T *__restrict__ E, const T (&in)[2 * P * BC + 1], T (&out)[P * BC + 1])
   {
 #pragma unroll
     for (int i = 0; i < P * BC + 1; ++i)
@@ -915,7 +917,7 @@ namespace mgamd
   }
   template <typename T, int P, int BC>
   __device__ __forceinline__ void
-  line_embed_sym(const double *__restrict__ Eh, const T (&in)[P * BC + 1], T (&out)[2 * P * BC + 1])
+  line_embed_sym(const T *__restrict__ Eh, const T (&in)[P * BC + 1], T (&out)[2 * P * BC + 1])
   {
 #pragma unroll
     for (int c = 0; c < BC; ++c)
@@ -939,7 +941,7 @@ namespace mgamd
   }
   template <typename T, int P, int BC>
   __device__ __forceinline__ void
-  line_embed_sym_T(const double *__restrict__ Eh, const T (&in)[2 * P * BC + 1], T (&out)[P * BC + 1])
+  line_embed_sym_T(const T *__restrict__ Eh, const T (&in)[2 * P * BC + 1], T (&out)[P * BC + 1])
   {
 #pragma unroll
     for (int i = 0; i < P * BC + 1; ++i)
@@ -973,7 +975,7 @@ namespace mgamd
   {
     const uint32_t *flags      = nullptr;
     const uint32_t *coarse_idx = nullptr;
-    double          Eh[(P + 1) * (P + 1)]; // rows 0..P of the 1D h-embedding (line_embed_sym)
+    T               Eh[(P + 1) * (P + 1)]; // rows 0..P of the 1D h-embedding (line_embed_sym)
     T              *coarse  = nullptr; // RESTRICT: the coarse defect (+=);  PROLONGATE: the coarse solution (read only)
     T              *x_inout = nullptr; // PROLONGATE: == src; x + P x_c of the fused bricks' interior DoFs is stored in place
     T              *scratch = nullptr; // PROLONGATE: x + P x_c of the shell DoFs a fused brick owns (indexed like x)
@@ -983,7 +985,7 @@ namespace mgamd
   struct ApplyArgs
   {
     SlotGroupDev g;
-    Mats<P>      m;
+    Mats<P, T>   m;
     const T     *src;
     T           *tail_acc; // [n_tail] accumulators of shell partial sums
     uint32_t     n_interior;

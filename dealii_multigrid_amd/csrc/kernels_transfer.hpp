@@ -26,8 +26,8 @@ namespace mgamd
     const uint16_t *coarse_mask; // [n_patches]
     const uint32_t *fine_idx;    // [n_patches][NF3]
     uint32_t        n_patches;
-    Mats<PC>        m;              // only I0/I1 are used (coarse hanging nodes)
-    double          E[NF * (PC + 1)]; // 1D embedding, rows = fine nodes
+    Mats<PC, T>     m;              // only I0/I1 are used (coarse hanging nodes)
+    T               E[NF * (PC + 1)]; // 1D embedding, rows = fine nodes
     const T        *src;
     T              *dst;
   };
@@ -314,7 +314,7 @@ namespace mgamd
     const uint16_t *coarse_mask; // [n_patches] hanging-node configuration of the coarse cell
     const uint32_t *fine_idx_t;  // [27][n_patches] owned fine DoF of fine node X + 3Y + 9Z, INVALID otherwise
     uint32_t        n_patches, max_uniq;
-    Mats<1>         m; // only I0/I1 are used
+    Mats<1, T>      m; // only I0/I1 are used
     const T        *src;
     T              *dst;
   };
@@ -500,7 +500,7 @@ namespace mgamd
     const uint32_t *coarse_idx;    // [n_bricks][NC3]
     const uint32_t *own_shell;     // [n_bricks][N_SHELL]
     uint32_t        n_bricks;
-    double          E[(2 * P + 1) * (P + 1)];
+    T               E[(2 * P + 1) * (P + 1)];
     const T        *src;
     T              *dst;
   };

@@ -60,14 +60,14 @@ namespace mgamd
     done[{ctx->device, kern}] = lds;
   }
 
-  // persistent workgroups for the one-slot-per-workgroup lattices (kernels.hpp, lattice_apply_persistent_body); not for
-  // float at p = 4, whose Chebyshev instantiation spills 35 registers
+  // persistent workgroups for the one-slot-per-workgroup lattices (kernels.hpp, lattice_apply_persistent_body); (until the
+  // constants of the float kernels became floats, Mats<P, T>, float at p = 4 spilled and was excluded)
   template <typename T, int P>
   inline bool
   use_persistent()
   {
     static const bool on = getenv("MGAMD_NO_PERSISTENT") == nullptr;
-    return on && !(P == 4 && std::is_same<T, float>::value);
+    return on;
   }
   inline bool
   use_cell_waves()
@@ -77,9 +77,9 @@ namespace mgamd
   }
   // two 4-wave workgroups with a 17^3 lattice pair each fit one CU; a multiple of 8 keeps a workgroup in its XCD's range
   inline int
-  resident_workgroups(const Ctx *ctx)
+  resident_workgroups(const Ctx *ctx, int per_cu = 2)
   {
-    return std::max(8, 2 * ctx->n_cu / 8 * 8);
+    return std::max(8, per_cu * ctx->n_cu / 8 * 8);
   }
 
   template <typename T, int P, int B, int MODE, bool CONSTR = false>
@@ -107,7 +107,7 @@ namespace mgamd
             // that a workgroup stays inside the Morton range of its XCD.  MGAMD_NO_PERSISTENT=1: one workgroup per slot.
             if (use_persistent<T, P>())
               {
-                const int resident = resident_workgroups(ctx);
+                const int resident = resident_workgroups(ctx, persistent_wgs_per_cu<T, P>());
                 auto      kern     = lattice_apply_persistent_kernel<T, P, B, MODE, CONSTR>;
                 ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), lds);
                 hipLaunchKernelGGL(kern, std::min(grid, resident), G::ABLOCK, lds, st, a);
@@ -443,10 +443,10 @@ namespace mgamd
     }
 
     template <int P>
-    Mats<P>
+    Mats<P, T>
     mats() const
     {
-      Mats<P>   m;
+      Mats<P, T> m;
       const int n = P + 1;
       for (int i = 0; i < n * n; ++i)
         {
@@ -456,7 +456,7 @@ namespace mgamd
           m.I1[i] = tables->fe.I[1][i];
         }
       constexpr int NH = Mats<P>::NH, NO = Mats<P>::NO;
-      auto          eo = [&](const double *A, double *Ae, double *Ao) {
+      auto          eo = [&](const double *A, T *Ae, T *Ao) {
         for (int i = 0; i < NH; ++i)
           for (int j = 0; j < NH; ++j)
             Ae[i * NH + j] = (j < NO) ? 0.5 * (A[i * n + j] + A[i * n + P - j]) : A[i * n + j];
@@ -464,8 +464,8 @@ namespace mgamd
           for (int j = 0; j < NO; ++j)
             Ao[i * NO + j] = 0.5 * (A[i * n + j] - A[i * n + P - j]);
       };
-      eo(m.M, m.Me, m.Mo);
-      eo(m.K, m.Ke, m.Ko);
+      eo(tables->fe.M.data(), m.Me, m.Mo);
+      eo(tables->fe.K.data(), m.Ke, m.Ko);
       return m;
     }
 
@@ -582,7 +582,7 @@ namespace mgamd
               throw std::runtime_error("brick pair launch: size not instantiated");
             }
           const size_t lds      = (2 * (size_t)G::N3 + 2 * P * P * P + 1) * sizeof(T);
-          const int    resident = resident_workgroups(ctx);
+          const int    resident = resident_workgroups(ctx, persistent_wgs_per_cu<T, P>());
           auto         kern     = lattice_apply_persistent_kernel<T, P, B, MODE>;
           ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), lds);
           hipLaunchKernelGGL(kern, std::min((int)a.g.n_slots, resident), G::ABLOCK, lds, st, a);
@@ -719,10 +719,7 @@ namespace mgamd
               apply_P<3, MODE>(src, epi, diag, words, edge_mode, fused);
             break;
           case 4:
-            if constexpr (FUSED_MODE && std::is_same<T, float>::value)
-              throw std::runtime_error("fused transfers: not instantiated for float at p = 4");
-            else
-              apply_P<4, MODE>(src, epi, diag, words, edge_mode, fused);
+            apply_P<4, MODE>(src, epi, diag, words, edge_mode, fused);
             break;
           default:
             throw std::runtime_error("degree not instantiated");

@@ -1,9 +1,9 @@
 import sys, os, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import dealii_multigrid_amd as m
 ctx = m.Context(0)
-for geo, L, p in [("quadrant", 8, 4), ("quadrant", 9, 1)]:
+for geo, L, p in [("quadrant", 8, 4), ("quadrant", 9, 1), ("hypercube", 9, 1)]:
     h = m.Hierarchy(ctx, geo, L, p, "HMG-global", coarse_solver="amg", number_type=m.F32)
     n = h.n_dofs
     b, z = m.Vector(ctx, n), m.Vector(ctx, n)   # double in/out, float levels
