@@ -661,7 +661,7 @@ namespace mgamd
               brick_constraint_passes<T, P, B, BLOCK>(bufA, args.m, tid, 1, args.g.fmask + slot, false, &fmcur);
           }
         // cell prefetch in the streamed sweeps (-4 % on the 2-4-word passes); the 5-word mode has no registers left for it
-        lattice_sweeps<T, P, B, BLOCK, NoHook, true, MODE != MODE_CHEB>(bufA, bufB, args.m, tid, 1, &hcur);
+        lattice_sweeps<T, P, B, BLOCK, NoHook, true, (MODE != MODE_CHEB || sizeof(T) == 4)>(bufA, bufB, args.m, tid, 1, &hcur);
         if constexpr (brick_may_be_constrained(B, CONSTR))
           if (any_hanging)
             brick_constraint_passes<T, P, B, BLOCK>(bufA, args.m, tid, 1, args.g.fmask + slot, true, &fmcur);

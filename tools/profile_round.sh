@@ -20,4 +20,11 @@ trace() { # geometry nref degree label
 trace quadrant 8 4 octant8_p4 && trace quadrant 9 1 octant9_p1 && trace hypercube 9 1 uniform9_p1 || exit 1
 timeout -k 10 300 python3 tools/perf_probe.py quadrant:8:4 quadrant:9:1 hypercube:9:1 hypercube:7:4 annulus:8:4 > $O/${tag}_stage_tables.txt 2>&1 || exit 1
 timeout -k 10 900 python3 bench.py > $O/${tag}_bench_octant8_p4.json 2> $O/${tag}_bench.err || exit 1
+# the same command under rocprofv3 --kernel-trace --stats (primary workload only): the kernel table whose average for the roofline
+# kernel must agree with the bench line's HIP-event figure
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_bs -o b -- python3 $R/bench.py --steps 10 --no-float --no-secondary --no-cpu-baseline \
+  > $O/${tag}_bench_octant8_p4_under_rocprof.json 2> $O/${tag}_bench_rocprof.err || exit 1
+cd $R
+cp $(find $O/${tag}_bs -name "*kernel_stats.csv" | head -1) $O/${tag}_bench_octant8_p4_kernel_stats.csv && rm -rf $O/${tag}_bs
 tail -c 600 $O/${tag}_bench_octant8_p4.json
