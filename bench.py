@@ -97,8 +97,7 @@ def run_workload(m, ctx, geometry, n_ref, degree, mg_type, coarse, steps, warmup
     if comm is None:
         N = [d.n_dofs for d in h.dofs]
     else:  # global level sizes: owned DoFs summed over the ranks (replicated levels are complete on every rank)
-        N = [int(round(comm.allreduce_sum(ctx, float(op.n_owned())))) if h.distributed[l] else h.dofs[l].n_dofs
-             for l, op in enumerate(h.operators)]
+        N = h.global_level_dofs(ctx)
     res = dict(n_dofs=h.n_dofs, n_cells=h.trias[-1].n_cells, n_levels=len(N), level_dofs=N, elapsed=elapsed, setup_s=setup_s,
                bytes_per_vcycle=algorithmic_bytes_per_vcycle(N, word=word), groups=h.dofs[-1].groups(), prof=prof,
                coarse_solver=h.mg.coarse_solver_used(),

@@ -150,15 +150,23 @@ def create_polynomial_coarsening_sequence(degree: int):
 class Partition:
     """Domain decomposition of a level hierarchy over n_ranks GPUs."""
 
-    def __init__(self, trias, n_ranks: int, hanging_weight: float = 2.0, min_root_cells: int = 0):
+    def __init__(self, trias, n_ranks: int, hanging_weight: float = 2.0, min_root_cells: int = 0, group: int = 1,
+                 min_sub_root_cells: int = 0):
+        """group > 1: two tiers -- levels below the root level with >= min_sub_root_cells cells are cut into n_ranks / group
+        parts, each held by `group` consecutive ranks (mgamd_partition_create_tiered)"""
         self.trias, self.n_ranks = list(trias), n_ranks
         arr = (C.c_void_p * len(self.trias))(*[t._h for t in self.trias])
         self._h = C.c_void_p()
-        _chk(_lib.mgamd_partition_create_ex(arr, len(self.trias), n_ranks, C.c_double(hanging_weight), C.c_uint64(min_root_cells),
-                                            C.byref(self._h)))
-        rl = C.c_uint()
+        _chk(_lib.mgamd_partition_create_tiered(arr, len(self.trias), n_ranks, C.c_double(hanging_weight), C.c_uint64(min_root_cells),
+                                                group, C.c_uint64(min_sub_root_cells), C.byref(self._h)))
+        rl, sl, g = C.c_uint(), C.c_uint(), C.c_uint()
         _chk(_lib.mgamd_partition_info(self._h, C.byref(rl), None))
-        self.root_level = rl.value
+        _chk(_lib.mgamd_partition_tiers(self._h, C.byref(sl), C.byref(g)))
+        self.root_level, self.sub_root_level, self.group = rl.value, sl.value, g.value
+
+    def n_parts(self, level: int) -> int:
+        """pieces the level is cut into: n_ranks, n_ranks / group on the subset levels, 1 on the replicated ones"""
+        return self.n_ranks if level >= self.root_level else (self.n_ranks // self.group if level >= self.sub_root_level else 1)
 
     def statistics(self):
         """MGTools::print_multigrid_statistics (ref:include/mg_tools.h:267-512) for this partition"""
@@ -357,6 +365,14 @@ class Communicator:
         h = C.c_void_p()
         _chk(_lib.mgamd_comm_rccl_create(ctx._h, n_ranks, rank, C.c_char_p(unique_id), C.byref(h)))
         return Communicator(h, n_ranks, rank)
+
+    def subset(self, group: int) -> "Communicator":
+        """communicator of a level that is cut into n_ranks / group parts (Partition tiers): rank = part"""
+        if group == 1:
+            return self
+        h = C.c_void_p()
+        _chk(_lib.mgamd_comm_subset(self._h, group, C.byref(h)))
+        return Communicator(h, self.n_ranks // group, self.rank // group, self)
 
     def allreduce_sum(self, ctx: "Context", value: float) -> float:
         r = C.c_double()
@@ -722,7 +738,7 @@ class DistributedHierarchy:
 
     def __init__(self, ctx: Context, comm: Communicator, geometry="quadrant", n_ref_global=3, degree=1, smoother_degree=3,
                  smoothing_range=20.0, eig_cg_n_iterations=20, coarse_solver="amg", number_type=F64, hanging_weight=2.0, max_brick=-1,
-                 min_root_dofs=4_000_000, mg_type="HMG-global", coarse_n_cycles=1):
+                 min_root_dofs=4_000_000, mg_type="HMG-global", coarse_n_cycles=1, subset_group=None, min_subset_dofs=1_000_000):
         self.ctx, self.comm = ctx, comm
         fine = geometry if isinstance(geometry, Triangulation) else Triangulation(geometry, n_ref_global)
         self.mesh_sequence = create_geometric_coarsening_sequence(fine)
@@ -740,17 +756,24 @@ class DistributedHierarchy:
         # levels below ~4 M DoFs stay replicated: their single-GPU time (latency-bound: 0.34 ms for 2.3 M DoFs at p=4,
         # 0.33 ms for 2.2 M at p=1) is below what a distributed level pays for its 8 halo exchanges per cycle on top of its
         # own (also latency-bound) kernels
+        # (round 3) levels between min_subset_dofs and min_root_dofs are cut into n_ranks / subset_group parts, each held by a
+        # group of ranks (Partition tiers): default groups of 4 from 8 ranks on, of 2 for 4-7 ranks
         p_low = min(p for _, p in plan)
-        self.partition = Partition(self.mesh_sequence, comm.n_ranks, hanging_weight, min_root_dofs // p_low ** 3)
+        if subset_group is None:
+            subset_group = 4 if comm.n_ranks % 4 == 0 and comm.n_ranks >= 8 else (2 if comm.n_ranks % 2 == 0 and comm.n_ranks >= 4 else 1)
+        self.partition = Partition(self.mesh_sequence, comm.n_ranks, hanging_weight, min_root_dofs // p_low ** 3, subset_group,
+                                   min_subset_dofs // p_low ** 3)
         sharded = comm.n_ranks > 1
+        sub_comm = comm.subset(self.partition.group) if self.partition.group > 1 else comm
+        self.level_comm = lambda mi: comm if mi >= self.partition.root_level else sub_comm
 
         def build(levels, shared_level0=None):
             """levels: list of (mesh index, degree); shared_level0: (dofs, operator, smoother) reused as the LAST level"""
             dofs = [DoFs(self.mesh_sequence[mi], p, max_brick, self.partition, mi, comm.rank) for mi, p in levels]
-            dist = [sharded and mi >= self.partition.root_level for mi, _ in levels]
+            dist = [sharded and mi >= self.partition.sub_root_level for mi, _ in levels]
             if shared_level0 is not None:
                 dofs[-1] = shared_level0[0]
-            ops = [Operator(ctx, d, number_type, comm if dist[l] else None) for l, d in enumerate(dofs)]
+            ops = [Operator(ctx, d, number_type, self.level_comm(levels[l][0]) if dist[l] else None) for l, d in enumerate(dofs)]
             if shared_level0 is not None:
                 ops[-1] = shared_level0[1]
             tr = [None] + [MGTwoLevelTransfer(ops[l], ops[l - 1]) for l in range(1, len(ops))]
@@ -763,7 +786,8 @@ class DistributedHierarchy:
         self.degrees = [p for _, p in plan]
         self.dofs, self.distributed, self.operators, self.transfers, self.smoothers = build(plan)
         self.coarse = None
-        n0 = (int(round(comm.allreduce_sum(ctx, float(self.operators[0].n_owned())))) if self.distributed[0] else self.dofs[0].n_dofs)
+        self.plan = plan
+        n0 = self.global_level_dofs(ctx)[0]
         if (coarse_solver == "gmg_vcycle" or (coarse_solver in AMG_COARSE_SOLVERS and self.distributed[0])) and n0 > 4096:
             # geometric stand-in for the AMG coarse solvers: the h-multigrid on level 0's space (mgamd.h, "gmg_vcycle"); the
             # algebraic multigrid is built from ONE rank's assembled matrix, so a sharded coarse level takes the stand-in
@@ -774,4 +798,13 @@ class DistributedHierarchy:
         self.mg = PreconditionMG(ctx, self.operators, self.transfers, self.smoothers, coarse_solver, self.coarse, coarse_n_cycles)
         self.fine_operator = self.operators[-1]
         self.n_local = self.dofs[-1].n_dofs
-        self.n_dofs = int(round(comm.allreduce_sum(ctx, float(self.fine_operator.n_owned()))))
+        self.n_dofs = self.global_level_dofs(ctx)[-1]
+
+    def global_level_dofs(self, ctx):
+        """DoFs per multigrid level: owned DoFs summed over the pieces of the level (replicated levels are complete on every rank)"""
+        return [int(round(self.level_comm(self.plan[l][0]).allreduce_sum(ctx, float(op.n_owned())))) if self.distributed[l]
+                else self.dofs[l].n_dofs for l, op in enumerate(self.operators)]
+
+    def layout(self):
+        """how many pieces every multigrid level is cut into (n_ranks, n_ranks / group on the subset tier, 1 = replicated)"""
+        return [self.partition.n_parts(mi) if self.comm.n_ranks > 1 else 1 for mi, _ in self.plan]

@@ -293,6 +293,26 @@ mgamd_comm_sim_create(mgamd_sim_group *g, unsigned rank, mgamd_comm **out)
 }
 
 int
+mgamd_comm_subset(mgamd_comm *base, unsigned group, mgamd_comm **out)
+{
+  MGAMD_TRY
+  if (!base || !base->comm || !out || group == 0)
+    throw std::invalid_argument("bad argument");
+  auto *c = new mgamd_comm;
+  try
+    {
+      c->comm = std::make_shared<SubsetComm>(base->comm, (int)group);
+    }
+  catch (...)
+    {
+      delete c;
+      throw;
+    }
+  *out = c;
+  MGAMD_CATCH
+}
+
+int
 mgamd_comm_destroy(mgamd_comm *c)
 {
   delete c;

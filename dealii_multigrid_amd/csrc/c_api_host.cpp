@@ -358,8 +358,15 @@ int
 mgamd_partition_create_ex(const mgamd_tria *const *trias, unsigned n_levels, unsigned n_ranks, double hanging_weight,
                           uint64_t min_root_cells, mgamd_partition **out)
 {
+  return mgamd_partition_create_tiered(trias, n_levels, n_ranks, hanging_weight, min_root_cells, 1, 0, out);
+}
+
+int
+mgamd_partition_create_tiered(const mgamd_tria *const *trias, unsigned n_levels, unsigned n_ranks, double hanging_weight,
+                              uint64_t min_root_cells, unsigned group, uint64_t min_sub_root_cells, mgamd_partition **out)
+{
   MGAMD_TRY
-  if (!trias || !out || n_levels == 0 || n_ranks == 0)
+  if (!trias || !out || n_levels == 0 || n_ranks == 0 || group == 0)
     throw std::invalid_argument("bad argument");
   auto                     *p = new mgamd_partition;
   std::vector<const Tria *> raw;
@@ -372,7 +379,7 @@ mgamd_partition_create_ex(const mgamd_tria *const *trias, unsigned n_levels, uns
     }
   try
     {
-      p->part = make_partition(raw, (int)n_ranks, hanging_weight, 32, (size_t)min_root_cells);
+      p->part = make_partition(raw, (int)n_ranks, hanging_weight, 32, (size_t)min_root_cells, (int)group, (size_t)min_sub_root_cells);
     }
   catch (...)
     {
@@ -404,6 +411,19 @@ mgamd_partition_info(const mgamd_partition *p, unsigned *root_level, unsigned *n
 }
 
 int
+mgamd_partition_tiers(const mgamd_partition *p, unsigned *sub_root_level, unsigned *group)
+{
+  MGAMD_TRY
+  if (!p)
+    throw std::invalid_argument("null argument");
+  if (sub_root_level)
+    *sub_root_level = (unsigned)p->part.sub_root_level;
+  if (group)
+    *group = (unsigned)p->part.group;
+  MGAMD_CATCH
+}
+
+int
 mgamd_partition_statistics(const mgamd_partition *p, double stats[5])
 {
   MGAMD_TRY
@@ -425,7 +445,7 @@ int
 mgamd_partition_get_owner(const mgamd_partition *p, unsigned level, uint16_t *owner)
 {
   MGAMD_TRY
-  if (!p || !owner || level >= p->trias.size() || (int)level < p->part.root_level)
+  if (!p || !owner || level >= p->trias.size() || (int)level < p->part.sub_root_level)
     throw std::invalid_argument("bad argument");
   const auto &o = p->part.level_owner((int)level);
   std::memcpy(owner, o.data(), o.size() * sizeof(uint16_t));
@@ -442,8 +462,10 @@ mgamd_dofs_create_local(const mgamd_partition *p, unsigned level, unsigned rank,
     throw std::invalid_argument("degree must be in [1," + std::to_string(MAX_DEGREE) + "]");
   auto *d    = new mgamd_dofs;
   d->tria    = p->trias[level];
-  d->n_ranks = p->part.n_ranks;
-  d->rank    = (int)rank;
+  // the level's pieces and the one this rank works on (subset levels: parts, shared by the ranks of a group)
+  const int np = p->part.n_parts((int)level), my = p->part.part_of((int)level, (int)rank);
+  d->n_ranks   = np;
+  d->rank      = my;
   try
     {
       if (p->part.replicated((int)level) || p->part.n_ranks == 1)
@@ -457,12 +479,12 @@ mgamd_dofs_create_local(const mgamd_partition *p, unsigned level, unsigned rank,
           const auto &owner = p->part.level_owner((int)level);
           d->owned          = std::make_shared<std::vector<uint8_t>>(owner.size());
           for (size_t c = 0; c < owner.size(); ++c)
-            (*d->owned)[c] = owner[c] == rank;
-          d->shared = std::make_shared<std::map<uint64_t, SharedInfo>>(shared_keys(*d->tria, owner, p->part.n_ranks, (int)rank, degree));
-          d->tables = std::make_shared<LevelTables>(*d->tria, degree, std::max(max_brick, 0), d->owned.get(), false, d->shared.get(), (int)rank);
-          if (max_brick < 0 && is_small_level(d->tria->n_cells() / p->part.n_ranks, degree) && n_nonempty_groups(*d->tables) > 1)
-            d->tables = std::make_shared<LevelTables>(*d->tria, degree, 1, d->owned.get(), false, d->shared.get(), (int)rank);
-          d->halo   = std::make_shared<HaloPlan>(make_halo_plan(*d->tables, *d->shared, p->part.n_ranks, (int)rank));
+            (*d->owned)[c] = owner[c] == my;
+          d->shared = std::make_shared<std::map<uint64_t, SharedInfo>>(shared_keys(*d->tria, owner, np, my, degree));
+          d->tables = std::make_shared<LevelTables>(*d->tria, degree, std::max(max_brick, 0), d->owned.get(), false, d->shared.get(), my);
+          if (max_brick < 0 && is_small_level(d->tria->n_cells() / np, degree) && n_nonempty_groups(*d->tables) > 1)
+            d->tables = std::make_shared<LevelTables>(*d->tria, degree, 1, d->owned.get(), false, d->shared.get(), my);
+          d->halo   = std::make_shared<HaloPlan>(make_halo_plan(*d->tables, *d->shared, np, my));
         }
     }
   catch (...)

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <condition_variable>
 #include <cstring>
 #include <memory>
@@ -215,6 +216,111 @@ namespace mgamd
           hipStreamSynchronize(stream) != hipSuccess)
         throw std::runtime_error("RcclComm: copy failed");
       return *h_scalar;
+    }
+  };
+  // ---------------------------------------------------------------------------------------------- rank subsets
+  // A level that is cut into n_parts = base->n_ranks / group parts, each held by `group` consecutive ranks which all do the
+  // part's work (Partition, two tiers).  To the level's operator, smoother and transfers this is an ordinary communicator of
+  // n_parts ranks: rank = part, the halo exchange with part q goes to the member of q's group with MY position in the group,
+  // and a sum over the parts is the base all-reduce divided by the group size (every part arrives `group` times; exact, the
+  // group size is a power of two).  replica_sum adds up the DIFFERENT partial vectors the members of one group hold after
+  // restricting from a level on which each of them has cells of its own (recursive doubling; a + b = b + a, so all members end
+  // with the same bits).
+  template <typename T>
+  __global__ void
+  subset_scale_kernel(T *__restrict__ x, T s, size_t n)
+  {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+      x[i] *= s;
+  }
+  template <typename T>
+  __global__ void
+  subset_add_kernel(T *__restrict__ x, const T *__restrict__ y, size_t n)
+  {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+      x[i] += y[i];
+  }
+  struct SubsetComm : Comm
+  {
+    std::shared_ptr<Comm> base;
+    int                   group = 1, index = 0; // ranks per part, my position in my part's group
+    void                 *tmp       = nullptr;
+    size_t                tmp_bytes = 0;
+    SubsetComm(std::shared_ptr<Comm> b, int g)
+      : base(std::move(b))
+      , group(g)
+    {
+      if (g < 1 || base->n_ranks % g != 0 || (g & (g - 1)) != 0)
+        throw std::invalid_argument("SubsetComm: the group size must be a power of two that divides the number of ranks");
+      n_ranks = base->n_ranks / g;
+      rank    = base->rank / g;
+      index   = base->rank % g;
+    }
+    ~SubsetComm() override
+    {
+      (void)hipFree(tmp);
+    }
+    static int
+    grid_for(size_t n)
+    {
+      return (int)std::min<size_t>((n + 255) / 256, 4096);
+    }
+    void
+    exchange(const void *send, void *recv, const std::vector<int> &peers, const std::vector<uint32_t> &offsets, size_t elem_size,
+             hipStream_t stream) override
+    {
+      std::vector<int> ranks(peers.size());
+      for (size_t j = 0; j < peers.size(); ++j)
+        ranks[j] = peers[j] * group + index;
+      base->exchange(send, recv, ranks, offsets, elem_size, stream);
+    }
+    void
+    allreduce_sum(void *buf, size_t n, int number_type, hipStream_t stream) override
+    {
+      base->allreduce_sum(buf, n, number_type, stream);
+      if (group > 1 && n > 0)
+        {
+          if (number_type == 8)
+            hipLaunchKernelGGL(subset_scale_kernel<double>, grid_for(n), 256, 0, stream, (double *)buf, 1.0 / group, n);
+          else
+            hipLaunchKernelGGL(subset_scale_kernel<float>, grid_for(n), 256, 0, stream, (float *)buf, 1.0f / group, n);
+        }
+    }
+    double
+    allreduce_sum_host(double v, hipStream_t stream) override
+    {
+      return base->allreduce_sum_host(v, stream) / group;
+    }
+    // buf <- sum over the members of my group of their buf (n elements of number_type bytes each, device memory)
+    void
+    replica_sum(void *buf, size_t n, int number_type, hipStream_t stream)
+    {
+      if (group == 1 || n == 0)
+        return;
+      const size_t bytes = n * (size_t)number_type;
+      if (bytes > tmp_bytes)
+        {
+          if (hipStreamSynchronize(stream) != hipSuccess)
+            throw std::runtime_error("SubsetComm: synchronisation failed");
+          (void)hipFree(tmp);
+          tmp       = nullptr;
+          tmp_bytes = 0;
+          if (hipMalloc(&tmp, bytes) != hipSuccess)
+            throw std::runtime_error("SubsetComm: allocation failed");
+          tmp_bytes = bytes;
+        }
+      const std::vector<uint32_t> offsets{0u, (uint32_t)n};
+      if (n > 0xFFFFFFFFull)
+        throw std::runtime_error("SubsetComm: vector too long");
+      for (int bit = 1; bit < group; bit <<= 1)
+        {
+          const std::vector<int> partner{base->rank ^ bit}; // same group: group-aligned blocks of a power-of-two size
+          base->exchange(buf, tmp, partner, offsets, (size_t)number_type, stream);
+          if (number_type == 8)
+            hipLaunchKernelGGL(subset_add_kernel<double>, grid_for(n), 256, 0, stream, (double *)buf, (const double *)tmp, n);
+          else
+            hipLaunchKernelGGL(subset_add_kernel<float>, grid_for(n), 256, 0, stream, (float *)buf, (const float *)tmp, n);
+        }
     }
   };
 } // namespace mgamd

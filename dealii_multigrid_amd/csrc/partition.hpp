@@ -23,28 +23,51 @@ namespace mgamd
 {
   struct Partition
   {
-    int                                n_ranks = 1;
-    int                                root_level = 0;               // index into the level list (coarse -> fine)
-    std::vector<std::vector<uint16_t>> owner;                        // per level >= root_level: owner of each cell
+    int n_ranks    = 1;
+    int root_level = 0; // index into the level list (coarse -> fine): levels >= root_level are cut into n_ranks chunks
+    // Two tiers (round 3): the levels [sub_root_level, root_level) are cut into n_ranks / group PARTS, and every part is held by
+    // the `group` consecutive ranks part * group ... part * group + group - 1, which all do its work (the same idea as the
+    // replicated levels below, applied to a rank subset: a level of 2-4 M DoFs costs a rank 1 / n_parts of its single-GPU time
+    // instead of all of it).  The cuts are nested: a rank's cells of the root level descend from its part's cells, so the level
+    // transfers stay rank-local; the partial sums of a restriction onto a part are summed over its group (SubsetComm::
+    // replica_sum).  group == 1: sub_root_level == root_level, no such levels.
+    int                                group = 1, sub_root_level = 0;
+    std::vector<std::vector<uint16_t>> owner; // per level >= sub_root_level: rank (levels >= root_level) or part of each cell
     const std::vector<uint16_t> &
     level_owner(int level) const
     {
-      return owner[level - root_level];
+      return owner[level - sub_root_level];
     }
     bool
     replicated(int level) const
     {
-      return level < root_level;
+      return level < sub_root_level;
+    }
+    bool
+    subset(int level) const
+    {
+      return level >= sub_root_level && level < root_level;
+    }
+    int
+    n_parts(int level) const // number of distinct pieces of the level
+    {
+      return replicated(level) ? 1 : (subset(level) ? n_ranks / group : n_ranks);
+    }
+    int
+    part_of(int level, int rank) const // the piece of the level that `rank` works on
+    {
+      return replicated(level) ? 0 : (subset(level) ? rank / group : rank);
     }
   };
 
   inline Partition
   make_partition(const std::vector<const Tria *> &trias, int n_ranks, double hanging_weight = 2.0, size_t min_cells_per_rank = 32,
-                 size_t min_root_cells = 0)
+                 size_t min_root_cells = 0, int group = 1, size_t min_sub_root_cells = 0)
   {
-    // min_root_cells: levels with fewer cells stay replicated.  A distributed level pays a halo exchange per operator
-    // application (latency of a pack kernel + grouped send/recv + combine kernel) whatever its size, a replicated one
-    // only its own, latency-bound, single-GPU time.
+    // min_root_cells: levels with fewer cells are not cut into n_ranks chunks.  A distributed level pays a halo exchange per
+    // operator application (latency of a pack kernel + grouped send/recv + combine kernel) whatever its size, a replicated one
+    // only its own, latency-bound, single-GPU time.  group > 1: levels below the root level with at least min_sub_root_cells
+    // cells are cut into n_ranks / group parts (see Partition).
     Partition P;
     P.n_ranks       = n_ranks;
     const int nl    = (int)trias.size();
@@ -57,47 +80,99 @@ namespace mgamd
         }
     if (root < 1)
       root = std::min(1, nl - 1);
-    P.root_level   = root;
-    const Tria &tr = *trias[root];
-    const Tria &tf = *trias[nl - 1];
-    // weights of the root cells
-    std::vector<double> w(tr.n_cells(), 0.0);
-    for (size_t c = 0; c < tf.n_cells(); ++c)
-      {
-        const Cell &fc  = tf.cells[c];
-        const int   anc = tr.find_leaf(fc.level, fc.i, fc.j, fc.k);
-        if (anc < 0)
-          throw std::runtime_error("partition: level meshes are not nested");
-        w[anc] += (tf.masks[c] >> MASK_FACE_SHIFT) ? hanging_weight : 1.0;
-      }
-    double total = 0;
-    for (double x : w)
-      total += x;
-    std::vector<uint16_t> root_owner(tr.n_cells());
-    double                acc = 0;
-    for (size_t c = 0; c < tr.n_cells(); ++c)
-      {
-        const double mid = acc + 0.5 * w[c];
-        int          r   = (int)(mid / total * n_ranks);
-        root_owner[c]    = (uint16_t)std::min(std::max(r, 0), n_ranks - 1);
-        acc += w[c];
-      }
-    P.owner.resize(nl - root);
-    P.owner[0] = root_owner;
-    for (int l = root + 1; l < nl; ++l)
-      {
-        const Tria &t = *trias[l];
-        auto       &o = P.owner[l - root];
-        o.resize(t.n_cells());
-        for (size_t c = 0; c < t.n_cells(); ++c)
+    P.root_level = root;
+    if (group < 1 || n_ranks % group != 0 || (group & (group - 1)) != 0)
+      throw std::invalid_argument("partition: the group size must be a power of two that divides the number of ranks");
+    if (group == n_ranks)
+      group = 1; // one part = a replicated level
+    const int n_parts = n_ranks / group;
+    int       sub     = root;
+    if (group > 1)
+      for (int l = 1; l < root; ++l)
+        if (trias[l]->n_cells() >= min_cells_per_rank * (size_t)n_parts && trias[l]->n_cells() >= min_sub_root_cells)
           {
-            const Cell &fc  = t.cells[c];
-            const int   anc = tr.find_leaf(fc.level, fc.i, fc.j, fc.k);
-            if (anc < 0)
-              throw std::runtime_error("partition: level meshes are not nested");
-            o[c] = root_owner[anc];
+            sub = l;
+            break;
           }
+    if (sub == root)
+      group = 1;
+    P.group          = group;
+    P.sub_root_level = sub;
+    const Tria &tf   = *trias[nl - 1];
+    // weight of every cell of `t`: the finest-level leaves below it, hanging-node cells weighted
+    auto weights = [&](const Tria &t) {
+      std::vector<double> w(t.n_cells(), 0.0);
+      for (size_t c = 0; c < tf.n_cells(); ++c)
+        {
+          const Cell &fc  = tf.cells[c];
+          const int   anc = t.find_leaf(fc.level, fc.i, fc.j, fc.k);
+          if (anc < 0)
+            throw std::runtime_error("partition: level meshes are not nested");
+          w[anc] += (tf.masks[c] >> MASK_FACE_SHIFT) ? hanging_weight : 1.0;
+        }
+      return w;
+    };
+    // cells [begin, end) of a level (Morton order) into `n` contiguous chunks of equal weight, numbered from `first`
+    auto cut = [&](const std::vector<double> &w, size_t begin, size_t end, int n, int first, std::vector<uint16_t> &out) {
+      double total = 0;
+      for (size_t c = begin; c < end; ++c)
+        total += w[c];
+      double acc = 0;
+      for (size_t c = begin; c < end; ++c)
+        {
+          const double mid = acc + 0.5 * w[c];
+          const int    r   = total > 0 ? (int)(mid / total * n) : 0;
+          out[c]           = (uint16_t)(first + std::min(std::max(r, 0), n - 1));
+          acc += w[c];
+        }
+    };
+    // owner of every cell of level l = owner of its ancestor on level `from`
+    auto inherit = [&](int l, const Tria &from, const std::vector<uint16_t> &from_owner) {
+      const Tria           &t = *trias[l];
+      std::vector<uint16_t> o(t.n_cells());
+      for (size_t c = 0; c < t.n_cells(); ++c)
+        {
+          const Cell &fc  = t.cells[c];
+          const int   anc = from.find_leaf(fc.level, fc.i, fc.j, fc.k);
+          if (anc < 0)
+            throw std::runtime_error("partition: level meshes are not nested");
+          o[c] = from_owner[anc];
+        }
+      return o;
+    };
+    P.owner.resize(nl - sub);
+    const Tria           &tr = *trias[root];
+    std::vector<uint16_t> root_owner(tr.n_cells());
+    const auto            w_root = weights(tr);
+    if (group == 1)
+      cut(w_root, 0, tr.n_cells(), n_ranks, 0, root_owner);
+    else
+      {
+        // parts on the sub-root level, inherited by the levels up to the root level; there every part's cells (a contiguous
+        // Morton range) are cut into `group` chunks
+        const Tria           &ts = *trias[sub];
+        std::vector<uint16_t> part(ts.n_cells());
+        cut(weights(ts), 0, ts.n_cells(), n_parts, 0, part);
+        P.owner[0] = part;
+        for (int l = sub + 1; l < root; ++l)
+          P.owner[l - sub] = inherit(l, ts, part);
+        const std::vector<uint16_t> root_part = inherit(root, ts, part);
+        size_t                      b         = 0;
+        while (b < root_part.size())
+          {
+            size_t e = b;
+            while (e < root_part.size() && root_part[e] == root_part[b])
+              ++e;
+            cut(w_root, b, e, group, (int)root_part[b] * group, root_owner);
+            b = e;
+          }
+        for (size_t c = 1; c < root_part.size(); ++c)
+          if (root_part[c] < root_part[c - 1])
+            throw std::runtime_error("partition: the cells of a part are not a contiguous Morton range");
       }
+    P.owner[root - sub] = root_owner;
+    for (int l = root + 1; l < nl; ++l)
+      P.owner[l - sub] = inherit(l, tr, root_owner);
     return P;
   }
 
@@ -126,12 +201,14 @@ namespace mgamd
       {
         const Tria         &t = *trias[l];
         std::vector<double> n(nr, 0.0);
+        const int grp = P.subset(l) ? P.group : 1; // a part's cells are worked on by every rank of its group
         if (P.replicated(l) || nr == 1)
           for (int r = 0; r < nr; ++r)
             n[r] = (double)t.n_cells();
         else
           for (uint16_t o : P.level_owner(l))
-            n[o] += 1.0;
+            for (int m = 0; m < grp; ++m)
+              n[o * grp + m] += 1.0;
         double mx = 0;
         for (double v : n)
           {
@@ -178,7 +255,7 @@ namespace mgamd
                             }
                       }
                 ranks &= ~(1ull << own[c]);
-                h_remote += (double)__builtin_popcountll(ranks);
+                h_remote += (double)(grp * __builtin_popcountll(ranks)); // (subset levels: every member of a neighbouring part)
               }
           }
         // vertical: children of the refined cells of level l on level l + 1
@@ -202,8 +279,8 @@ namespace mgamd
                       { // replicated parent, distributed child: local for the child's owner, remote for nobody
                         v_local += 1;
                       }
-                    else if (P.level_owner(l)[c] == P.level_owner(l + 1)[*f])
-                      v_local += 1;
+                    else if (P.part_of(l, P.level_owner(l + 1)[*f] * (P.subset(l + 1) ? P.group : 1)) == P.level_owner(l)[c])
+                      v_local += 1; // (owner of the child, as a rank, works on the parent's piece: nested cuts)
                     else
                       v_remote += 1;
                   }

@@ -1006,7 +1006,20 @@ namespace mgamd
     void
     finish_restriction(T *dst_coarse)
     {
-      // sharded runs: complete the coarse defect across ranks
+      // sharded runs: complete the coarse defect across ranks.  Onto a level that is cut into fewer pieces than the fine one (a
+      // part held by a group of ranks, Partition tiers): every member of the group has restricted the cells of its own, so the
+      // members' vectors are summed first; then the shared DoFs between the parts
+      if (auto *sc = dynamic_cast<SubsetComm *>(cop->comm.get()))
+        {
+          auto     *sf = dynamic_cast<SubsetComm *>(fop->comm.get());
+          const int gf = sf ? sf->group : (fop->comm ? 1 : sc->group);
+          if (gf != sc->group)
+            {
+              if (gf != 1)
+                throw std::runtime_error("restriction between two rank-subset tiers of different group sizes is not supported");
+              sc->replica_sum(dst_coarse, cop->n_dofs(), (int)sizeof(T), ctx->stream);
+            }
+        }
       if (cop->halo)
         cop->exchange_add_raw(dst_coarse + cop->tables->n_interior);
       else if (fop->comm)

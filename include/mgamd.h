@@ -148,6 +148,15 @@ int mgamd_partition_create(const mgamd_tria *const *trias, unsigned n_levels, un
  * per operator application whatever its size) */
 int mgamd_partition_create_ex(const mgamd_tria *const *trias, unsigned n_levels, unsigned n_ranks, double hanging_weight,
                               uint64_t min_root_cells, mgamd_partition **out);
+/* Two tiers (csrc/partition.hpp): levels below the root level with at least min_sub_root_cells cells are cut into
+ * n_ranks / group PARTS, each held (and worked on) by `group` consecutive ranks -- the counterpart of the reference's
+ * agglomeration of coarse levels onto fewer processes (ref:multigrid_throughput.cc:379-418,1464-1501), without idle ranks.
+ * group: a power of two that divides n_ranks; 1 = mgamd_partition_create_ex.  mgamd_partition_tiers reports the first such level
+ * (== root level if there is none) and the group size; mgamd_dofs_create_local / mgamd_partition_get_owner accept those levels
+ * (owners are part numbers there); their operators take mgamd_comm_subset(comm, group). */
+int mgamd_partition_create_tiered(const mgamd_tria *const *trias, unsigned n_levels, unsigned n_ranks, double hanging_weight,
+                                  uint64_t min_root_cells, unsigned group, uint64_t min_sub_root_cells, mgamd_partition **out);
+int mgamd_partition_tiers(const mgamd_partition *p, unsigned *sub_root_level, unsigned *group);
 int mgamd_partition_destroy(mgamd_partition *p);
 /* MGTools::print_multigrid_statistics for this partition (ref:include/mg_tools.h:267-512; verbose-mode table columns
  * workload_eff, workload_path_max, vertical_eff, horizontal_eff, mem_total: ref:multigrid_throughput.cc:1657-1665), in that
@@ -190,6 +199,9 @@ int mgamd_comm_rccl_create(mgamd_ctx *ctx, unsigned n_ranks, unsigned rank, cons
 int mgamd_sim_group_create(unsigned n_ranks, mgamd_sim_group **out);
 int mgamd_sim_group_destroy(mgamd_sim_group *g);
 int mgamd_comm_sim_create(mgamd_sim_group *g, unsigned rank, mgamd_comm **out);
+/* the communicator of a level that is cut into n_ranks / group parts (mgamd_partition_create_tiered): rank = part, halo peers are
+ * parts, sums over the parts; keeps `base` alive */
+int mgamd_comm_subset(mgamd_comm *base, unsigned group, mgamd_comm **out);
 int mgamd_comm_destroy(mgamd_comm *c);
 /* sum of a host scalar over all ranks (blocking) */
 int mgamd_comm_allreduce_sum(mgamd_comm *c, mgamd_ctx *ctx, double value, double *result);

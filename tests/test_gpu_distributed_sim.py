@@ -205,3 +205,47 @@ def test_sharded_solve_matches_single_rank(mgamd, geo, L, p, n_ranks):
                 assert abs(seen[k] - v) <= 1e-12 * max(1.0, abs(v))
             seen[k] = v
     assert len(seen) == h0.n_dofs
+
+
+@pytest.mark.parametrize("geo,L,p,mg_type,n_ranks,group", [("quadrant", 5, 2, "HMG-global", 8, 4), ("quadrant", 6, 1, "HMG-global", 8, 2),
+                                                           ("annulus", 6, 1, "HMG-global", 4, 2), ("quadrant", 4, 4, "HPMG", 4, 2)])
+def test_two_tier_hierarchy_matches_numpy_oracle(mgamd, oracle, geo, L, p, mg_type, n_ranks, group):
+    """Partition tiers (round 3): the finest levels cut into n_ranks chunks, the levels below into n_ranks / group parts that a group
+    of ranks holds together (SubsetComm: halo exchange between parts, sums over the parts, group sum after the restriction from the
+    finer tier), the rest replicated -- V-cycle, solve and iteration count against the independent numpy oracle."""
+    levels, P = oracle.build_hierarchy(geo, L, p, mg_type)
+    omg = oracle.Multigrid(levels, P, 3, coarse="direct", start_vectors=[oracle.key_hash_start_vector(lv) for lv in levels])
+    Lf = levels[-1]
+    kf = {tuple(int(v) for v in k): i for i, k in enumerate(Lf.keys)}
+    r = key_vector(Lf.keys, 2)
+    r[Lf.constrained] = 0.0
+    zref = omg.vcycle(r)
+    xref, itref, hist = oracle.pcg(Lf.A, Lf.rhs_constant, omg.vcycle, 1e-4)
+    sim = mgamd.SimGroup(n_ranks)
+    # tiers by size: the two finest meshes on all ranks, the two below them on the parts
+    seq = mgamd.create_geometric_coarsening_sequence(mgamd.Triangulation(geo, L))
+    n_cells = [t.n_cells for t in seq]
+    p_low = min(lv.p for lv in levels)
+
+    def rank_main(rk):
+        ctx = mgamd.Context(0)
+        h = mgamd.DistributedHierarchy(ctx, sim.comm(rk), geo, L, p, coarse_solver="amg", max_brick=0, mg_type=mg_type, subset_group=group,
+                                       min_root_dofs=n_cells[-2] * p_low ** 3, min_subset_dofs=n_cells[-4] * p_low ** 3)
+        keys = keyset(h.dofs[-1].keys())
+        idx = np.array([kf[k] for k in keys])
+        op = h.fine_operator
+        vr, vz = op.initialize_dof_vector().from_host(r[idx]), op.initialize_dof_vector()
+        h.mg.vmult(vz, vr)
+        b, x = op.initialize_dof_vector(), op.initialize_dof_vector()
+        op.rhs(b)
+        it, res = mgamd.solve_cg(op, h.mg, x, b, 1e-4)
+        return dict(idx=idx, z=vz.to_host(), x=x.to_host(), it=it, n_dofs=h.n_dofs, layout=h.layout(), level_dofs=h.global_level_dofs(ctx),
+                    group=h.partition.group)
+
+    out = run_ranks(n_ranks, rank_main)
+    for o in out:
+        assert o["group"] == group and n_ranks // group in o["layout"] and o["layout"][0] == 1 and o["layout"][-1] == n_ranks
+        assert o["level_dofs"] == [lv.n for lv in levels]  # every DoF of every level owned exactly once
+        assert rel_err(o["z"], zref[o["idx"]]) < 1e-11
+        assert o["it"] == itref
+        assert rel_err(o["x"], xref[o["idx"]]) < 1e-10

@@ -193,3 +193,60 @@ def test_halo_slots_come_first(mgamd, geo, L, p, n_ranks):
                 assert sl < nh, (g, sl, nh)  # every slot touching a shared tail DoF is in the halo part
             n_front += sl < nh
         assert 0 < n_front < len(touches)  # and there is an interior part to overlap with
+
+
+@pytest.mark.parametrize("geo,L,n_ranks,group", [("quadrant", 6, 8, 4), ("quadrant", 6, 8, 2), ("annulus", 7, 4, 2), ("hypercube", 5, 8, 4)])
+def test_two_tier_partition_is_nested_and_balanced(mgamd, geo, L, n_ranks, group):
+    """Partition tiers (csrc/partition.hpp; the counterpart of the reference's agglomeration of coarse levels onto fewer processes,
+    ref:multigrid_throughput.cc:379-418,1464-1501): the levels [sub_root_level, root_level) are cut into n_ranks / group parts, the
+    cuts are nested (every cell of a rank on the root level and above descends from a cell of the rank's part), parts and ranks are
+    contiguous Morton ranges, and the weights are balanced on both tiers."""
+    trias = mgamd.create_geometric_coarsening_sequence(mgamd.Triangulation(geo, L))
+    nl = len(trias)
+    # root level = the finest but one, parts from two levels below it
+    part = mgamd.Partition(trias, n_ranks, 2.0, min_root_cells=trias[nl - 2].n_cells, group=group, min_sub_root_cells=trias[nl - 4].n_cells)
+    n_parts = n_ranks // group
+    # (a level also needs 32 cells per piece, like the root level)
+    sub_expected = next(l for l in range(1, nl - 1) if trias[l].n_cells >= max(32 * n_parts, trias[nl - 4].n_cells))
+    assert part.group == group and part.root_level == nl - 2 and part.sub_root_level == sub_expected < nl - 2
+    assert [part.n_parts(l) for l in range(nl)] == [1] * sub_expected + [n_parts] * (nl - 2 - sub_expected) + [n_ranks] * 2
+    plain = mgamd.Partition(trias, n_ranks, 2.0, min_root_cells=trias[nl - 2].n_cells)
+    assert plain.group == 1 and plain.sub_root_level == plain.root_level == nl - 2
+    cells = []
+    for t in trias:
+        lev, i, j, k, mask = t.cells()
+        cells.append((lev.astype(np.int64), i.astype(np.int64), j.astype(np.int64), k.astype(np.int64), mask))
+
+    def ancestor_owner(lc, lf):
+        """owner (on level mesh lc) of the ancestor of every cell of level mesh lf"""
+        lev, i, j, k, _ = cells[lc]
+        table = {(a, b, c, d): o for a, b, c, d, o in zip(lev.tolist(), i.tolist(), j.tolist(), k.tolist(), part.owner(lc).tolist())}
+        out = []
+        for a, b, c, d in zip(*[x.tolist() for x in cells[lf][:4]]):
+            while (a, b, c, d) not in table:
+                a, b, c, d = a - 1, b >> 1, c >> 1, d >> 1
+            out.append(table[(a, b, c, d)])
+        return np.array(out)
+
+    for l in range(part.sub_root_level, nl):
+        o = part.owner(l)
+        assert set(np.unique(o)) == set(range(part.n_parts(l)))
+        assert np.all(np.diff(o.astype(np.int64)) >= 0)  # contiguous Morton ranges, ascending
+    # nesting: part of a root-level rank = rank // group; the subset levels inherit the parts; finer levels inherit the ranks
+    sub, root = part.sub_root_level, part.root_level
+    for l in range(sub + 1, nl):
+        assert np.array_equal(ancestor_owner(sub, l), part.owner(l) // (group if l >= root else 1))
+    assert np.array_equal(ancestor_owner(root, nl - 1), part.owner(nl - 1))
+    # balance of the finest-level weights (hanging-node cells x 2) over the ranks and over the parts
+    w = np.where((cells[-1][4] >> 3) != 0, 2.0, 1.0)
+    of = part.owner(nl - 1)
+    load_r = np.array([w[of == r].sum() for r in range(n_ranks)])
+    load_p = np.array([w[of // group == q].sum() for q in range(n_parts)])
+    assert load_p.max() / load_p.mean() < 1.15 and load_r.max() / load_r.mean() < 1.25
+    # local tables of a subset level: the ranks of one group get the same piece, the halo peers are parts
+    d = [mgamd.DoFs(trias[sub], 2, 0, part, sub, r) for r in range(n_ranks)]
+    for r in range(n_ranks):
+        assert d[r].n_dofs == d[(r // group) * group].n_dofs
+        assert all(0 <= q < n_parts and q != r // group for q in d[r].halo_plan()["peers"])
+    st = part.statistics()
+    assert st["vertical_eff"] == 1.0 and 0 < st["workload_eff"] <= 1.0
