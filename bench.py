@@ -52,7 +52,7 @@ def algorithmic_bytes_per_vcycle(n_dofs_per_level, k=3, word=8):
 
 
 def run_workload(m, ctx, geometry, n_ref, degree, mg_type, coarse, steps, warmup, barrier, sync, profile, comm=None, details=False,
-                 number_type=None, diagnostics=False, coarse_cycles=1):
+                 number_type=None, diagnostics=False, coarse_cycles=1, subset_group=None):
     t0 = time.time()
     number_type = m.F64 if number_type is None else number_type
     word = 8 if number_type == m.F64 else 4
@@ -61,7 +61,7 @@ def run_workload(m, ctx, geometry, n_ref, degree, mg_type, coarse, steps, warmup
                         coarse_n_cycles=coarse_cycles)
     else:
         h = m.DistributedHierarchy(ctx, comm, geometry, n_ref, degree, mg_type=mg_type, smoother_degree=3, coarse_solver=coarse,
-                                   number_type=number_type, coarse_n_cycles=coarse_cycles)
+                                   number_type=number_type, coarse_n_cycles=coarse_cycles, subset_group=subset_group)
     # PreconditionMG::vmult acts on the OUTER vectors, which are double whatever MGNumberType is (ref:multigrid_throughput.cc:
     # 2430-2433 run<3, 1, double, MGNumber>): with float levels copy_to_mg / copy_from_mg cast
     if number_type == m.F64:
@@ -102,6 +102,9 @@ def run_workload(m, ctx, geometry, n_ref, degree, mg_type, coarse, steps, warmup
                bytes_per_vcycle=algorithmic_bytes_per_vcycle(N, word=word), groups=h.dofs[-1].groups(), prof=prof,
                coarse_solver=h.mg.coarse_solver_used(),
                fused_transfer_bricks=sum(t.n_fused_bricks() for t in h.transfers[1:] if t is not None))
+    if comm is not None:
+        # pieces every level is cut into: n_ranks, n_ranks / group on the subset tier (each part held by a group of ranks), 1 = replicated
+        res["level_layout"], res["subset_group"] = h.layout(), h.partition.group
     if diag is not None:
         res["rccl_diagnostics"] = diag
     if comm is not None:
@@ -292,6 +295,8 @@ def main():
     ap.add_argument("--coarse-cycles", type=int, default=None, help="CoarseSolverNCycles (amg, cg_with_amg, gmg_vcycle); default 2 for "
                     "pmg_annulus with amg (the reference's default.json), else 1")
     ap.add_argument("--mode", choices=["sharded", "replicas"], default="sharded", help="N > 1: domain decomposition (default) or replicas")
+    ap.add_argument("--subset-group", type=int, default=None, help="N > 1: ranks per part on the subset tier of the partition (levels of 1-4 M "
+                    "DoFs are cut into N / group parts; default 4 from 8 ranks on, 2 from 4 on; 1 = replicate those levels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
@@ -335,7 +340,7 @@ def main():
             dist.broadcast(uid, 0)
             comm = m.Communicator.rccl(ctx, world, rank, bytes(uid.cpu().numpy().tobytes()))
         prim = run_workload(m, ctx, geometry, nref, degree, mg_type, coarse, args.steps, args.warmup, barrier, sync, profile=True, comm=comm,
-                            details=world == 1, diagnostics=True, coarse_cycles=args.coarse_cycles)
+                            details=world == 1, diagnostics=True, coarse_cycles=args.coarse_cycles, subset_group=args.subset_group)
     except Exception as e:  # noqa: BLE001
         # no fallback, no relabelled metric: the other ranks may be blocked inside a collective, so leave hard with a
         # non-zero status and let the launcher tear the job down
@@ -374,7 +379,8 @@ def main():
                         f"(BASELINE.json {cfg_name})" + collapsed,
             "n_dofs": prim["n_dofs"], "n_cells": prim["n_cells"], "n_levels": prim["n_levels"], "level_dofs": prim["level_dofs"],
             "parallelism": "1 GPU" if world == 1 else (
-                f"domain decomposition over {world} GPUs: RCCL send/recv halo exchange + all-reduce onto replicated coarse levels"
+                f"domain decomposition over {world} GPUs: RCCL send/recv halo exchange, rank-group tier for the mid-size levels (level_layout), "
+                f"all-reduce onto the replicated coarse levels"
                 if mode == "sharded" else f"replicas x{world} (no data-path collective)"),
             "cg_iterations_reltol_1e-4": prim["cg_iterations"],
             "cg_throughput_dofs_x_iterations_per_s": prim["cg_throughput"],
@@ -386,6 +392,9 @@ def main():
     if "ms_no_collapse" in prim:
         out["ms_per_step_no_collapse"] = prim["ms_no_collapse"]
     out["config"]["fused_transfer_bricks"] = prim["fused_transfer_bricks"]
+    if "level_layout" in prim:
+        out["config"]["level_layout"] = prim["level_layout"]  # pieces per level, coarse -> fine (tiers)
+        out["config"]["subset_group"] = prim["subset_group"]
     if "halo" in prim:
         out["config"]["halo_rank0"] = prim["halo"]
     if "rccl_diagnostics" in prim:
@@ -429,7 +438,8 @@ def main():
         sharded2 = mode == "sharded"
         try:
             sec = run_workload(m, ctx, "quadrant", args.nref_p1, 1, "HMG-global", "amg", args.steps, args.warmup,
-                               barrier if sharded2 else (lambda: None), sync, profile=False, comm=comm if sharded2 else None, details=world == 1)
+                               barrier if sharded2 else (lambda: None), sync, profile=False, comm=comm if sharded2 else None, details=world == 1,
+                               subset_group=args.subset_group)
         except Exception as e:  # noqa: BLE001
             print(f"bench.py: rank {rank}/{world} failed in the p=1 workload: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
             os._exit(3)

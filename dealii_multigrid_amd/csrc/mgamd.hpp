@@ -164,23 +164,41 @@ namespace mgamd
   class Partition
   {
   public:
+    // group > 1: two tiers -- levels below the root level with >= min_sub_root_cells cells are cut into n_ranks / group parts, each
+    // held by `group` consecutive ranks (what the reference's agglomeration onto fewer processes is for,
+    // ref:multigrid_throughput.cc:379-418,1464-1501); their operators take Communicator::subset(group)
     Partition(const std::vector<std::shared_ptr<const Triangulation>> &triangulations, unsigned n_ranks, double hanging_weight = 2.0,
-              uint64_t min_root_cells = 0)
+              uint64_t min_root_cells = 0, unsigned group = 1, uint64_t min_sub_root_cells = 0)
       : triangulations(triangulations)
     {
       std::vector<const mgamd_tria *> t;
       for (const auto &x : triangulations)
         t.push_back(x->get());
       mgamd_partition *p = nullptr;
-      check(mgamd_partition_create_ex(t.data(), (unsigned)t.size(), n_ranks, hanging_weight, min_root_cells, &p));
+      check(mgamd_partition_create_tiered(t.data(), (unsigned)t.size(), n_ranks, hanging_weight, min_root_cells, group, min_sub_root_cells, &p));
       h.reset(p, mgamd_partition_destroy);
-      unsigned nr = 0;
       check(mgamd_partition_info(h.get(), &root, &nr));
+      check(mgamd_partition_tiers(h.get(), &sub_root, &grp));
     }
     unsigned
     root_level() const
     {
       return root;
+    }
+    unsigned
+    sub_root_level() const // == root_level() without a subset tier
+    {
+      return sub_root;
+    }
+    unsigned
+    group() const
+    {
+      return grp;
+    }
+    unsigned
+    n_parts(unsigned level) const // pieces of the level: n_ranks, n_ranks / group on the subset tier, 1 = replicated
+    {
+      return level >= root ? nr : (level >= sub_root ? nr / grp : 1);
     }
     mgamd_partition *
     get() const
@@ -191,7 +209,7 @@ namespace mgamd
 
   private:
     std::shared_ptr<mgamd_partition> h;
-    unsigned                         root = 0;
+    unsigned                         root = 0, sub_root = 0, grp = 1, nr = 1;
   };
 
   class DoFHandler
@@ -310,6 +328,21 @@ namespace mgamd
       c.h.reset(m, mgamd_comm_destroy);
       c.n = n_ranks;
       c.r = rank;
+      return c;
+    }
+    // the communicator of the levels that are cut into n_ranks / group parts (Partition tiers): rank = part
+    Communicator
+    subset(unsigned group) const
+    {
+      if (group <= 1)
+        return *this;
+      Communicator c;
+      mgamd_comm  *m = nullptr;
+      check(mgamd_comm_subset(h.get(), group, &m));
+      const std::shared_ptr<mgamd_comm> base = h; // (the C object keeps the base alive as well)
+      c.h.reset(m, [base](mgamd_comm *x) { mgamd_comm_destroy(x); });
+      c.n = n / group;
+      c.r = r / group;
       return c;
     }
     double

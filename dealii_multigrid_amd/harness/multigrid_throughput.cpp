@@ -327,12 +327,21 @@ run(const Context &ctx, const RunParameters &params, ConvergenceTable &table, co
   const bool local_smoothing = params.type == "HMG-local";
   if (comm && params.type != "HMG-global")
     throw std::runtime_error("sharded harness: Type '" + params.type + "' is not implemented (HMG-global is)");
-  // levels below ~4 M DoFs stay replicated
+  // levels of >= ~4 M DoFs are cut into one chunk per rank, those of >= ~1 M DoFs into n_ranks / group parts that a group of ranks
+  // holds together (groups of 4 from 8 ranks on, of 2 from 4 on), the others are replicated (the counterpart
+  // of the reference's min_level / min_n_cells_per_process agglomeration, ref:multigrid_throughput.cc:379-418,1464-1501)
   std::unique_ptr<Partition> partition;
+  Communicator               sub_comm;
   if (comm)
-    partition = std::make_unique<Partition>(triangulations, comm->n_ranks(), 2.0,
-                                            (uint64_t)4000000 / ((uint64_t)params.fe_degree_fine * params.fe_degree_fine * params.fe_degree_fine));
-  auto distributed = [&](unsigned l) { return comm && comm->n_ranks() > 1 && l >= partition->root_level(); };
+    {
+      const uint64_t p3    = (uint64_t)params.fe_degree_fine * params.fe_degree_fine * params.fe_degree_fine;
+      const unsigned nr    = comm->n_ranks();
+      const unsigned group = (nr >= 8 && nr % 4 == 0) ? 4 : ((nr >= 4 && nr % 2 == 0) ? 2 : 1);
+      partition            = std::make_unique<Partition>(triangulations, nr, 2.0, (uint64_t)4000000 / p3, group, (uint64_t)1000000 / p3);
+      sub_comm             = comm->subset(partition->group());
+    }
+  auto distributed = [&](unsigned l) { return comm && comm->n_ranks() > 1 && l >= partition->sub_root_level(); };
+  auto level_comm  = [&](unsigned l) -> const Communicator  *{ return l >= partition->root_level() ? comm : &sub_comm; };
 
   const bool hp_local        = params.type == "HPMG-local";
   PreconditionChebyshev::AdditionalData sd;
@@ -383,7 +392,7 @@ run(const Context &ctx, const RunParameters &params, ConvergenceTable &table, co
   const DoFHandler &fine_dof_handler = local_smoothing ? *active_dof_handler : dof_handlers.back();
   for (unsigned l = 0; l < n_levels; ++l)
     if (comm)
-      operators[l].reinit(ctx, dof_handlers[l], level_number_type, distributed(l) ? comm : nullptr);
+      operators[l].reinit(ctx, dof_handlers[l], level_number_type, distributed(l) ? level_comm(l) : nullptr);
     else
       operators[l].reinit(ctx, dof_handlers[l], level_number_type);
   for (unsigned l = 1; l < n_levels; ++l)
@@ -431,11 +440,11 @@ run(const Context &ctx, const RunParameters &params, ConvergenceTable &table, co
   if (level_number_type == MGAMD_F64 && !local_smoothing)
     op = operators.back();
   else if (comm)
-    op.reinit(ctx, fine_dof_handler, MGAMD_F64, distributed(n_levels - 1) ? comm : nullptr);
+    op.reinit(ctx, fine_dof_handler, MGAMD_F64, distributed(n_levels - 1) ? level_comm(n_levels - 1) : nullptr);
   else
     op.reinit(ctx, fine_dof_handler, MGAMD_F64);
   // DoFHandler::n_dofs() of the GLOBAL problem
-  const uint64_t n_dofs_global = (comm && distributed(n_levels - 1)) ? (uint64_t)std::llround(comm->allreduce_sum(ctx, (double)op.n_owned())) :
+  const uint64_t n_dofs_global = (comm && distributed(n_levels - 1)) ? (uint64_t)std::llround(level_comm(n_levels - 1)->allreduce_sum(ctx, (double)op.n_owned())) :
                                                                        fine_dof_handler.n_dofs();
   Vector solution, rhs;
   op.initialize_dof_vector(solution);
@@ -450,6 +459,7 @@ run(const Context &ctx, const RunParameters &params, ConvergenceTable &table, co
   table.add_value("n_ref_global", params.n_ref_global);
   table.add_value("n_ref_local", params.n_ref_local);
   table.add_value("n_dofs", n_dofs_global);
+  // (the reference: the ranks that own cells of the coarsest level, ref:multigrid_throughput.cc:1464-1488; here every rank holds it)
   table.add_value("sub_comm_size", comm ? comm->n_ranks() : 1);
 
   if (params.verbose)
