@@ -314,9 +314,17 @@ def main():
     import torch
 
     dist = None
-    if world > 1:
+    # MGAMD_BENCH_FORCE_SHARDED=1 (development): run the N > 1 code path -- RCCL communicator, DistributedHierarchy, diagnostics,
+    # gathers -- with ONE rank, which is all a one-GPU box can execute of it (RCCL refuses two ranks on one device)
+    force_sharded = world == 1 and os.environ.get("MGAMD_BENCH_FORCE_SHARDED") == "1"
+    if world > 1 or force_sharded:
         import torch.distributed as dist
 
+        if force_sharded:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -330,7 +338,7 @@ def main():
     import dealii_multigrid_amd as m
 
     ctx = m.Context(local_rank)
-    mode = "single" if world == 1 else args.mode
+    mode = "single" if (world == 1 and not force_sharded) else args.mode
     comm = None
     try:
         if mode == "sharded":
