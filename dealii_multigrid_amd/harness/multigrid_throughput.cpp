@@ -325,8 +325,20 @@ run(const Context &ctx, const RunParameters &params, ConvergenceTable &table, co
   else
     throw std::runtime_error("Type '" + params.type + "': not implemented");
   const bool local_smoothing = params.type == "HMG-local";
-  if (comm && params.type != "HMG-global")
-    throw std::runtime_error("sharded harness: Type '" + params.type + "' is not implemented (HMG-global is)");
+  if (comm && !(params.type == "HMG-global" || params.type == "PMG" || params.type == "HPMG"))
+    throw std::runtime_error("sharded harness: Type '" + params.type + "' is not implemented (HMG-global, PMG and HPMG are)");
+  // the geometric meshes the partition is built on, and the mesh of every multigrid level: the p-levels of PMG / HPMG live on the
+  // finest mesh and inherit its partition (ref:multigrid_throughput.cc:1506-1571)
+  std::vector<std::shared_ptr<const Triangulation>> mesh_sequence = triangulations;
+  std::vector<unsigned>                             mesh_index(triangulations.size());
+  for (unsigned l = 0; l < mesh_index.size(); ++l)
+    mesh_index[l] = l;
+  if (comm && (params.type == "PMG" || params.type == "HPMG"))
+    {
+      mesh_sequence = create_geometric_coarsening_sequence(tria);
+      for (unsigned l = 0; l < mesh_index.size(); ++l)
+        mesh_index[l] = params.type == "PMG" ? (unsigned)mesh_sequence.size() - 1 : std::min<unsigned>(l, (unsigned)mesh_sequence.size() - 1);
+    }
   // levels of >= ~4 M DoFs are cut into one chunk per rank, those of >= ~1 M DoFs into n_ranks / group parts that a group of ranks
   // holds together (groups of 4 from 8 ranks on, of 2 from 4 on), the others are replicated (the counterpart
   // of the reference's min_level / min_n_cells_per_process agglomeration, ref:multigrid_throughput.cc:379-418,1464-1501)
@@ -334,14 +346,18 @@ run(const Context &ctx, const RunParameters &params, ConvergenceTable &table, co
   Communicator               sub_comm;
   if (comm)
     {
-      const uint64_t p3    = (uint64_t)params.fe_degree_fine * params.fe_degree_fine * params.fe_degree_fine;
+      const uint64_t p_low = *std::min_element(degrees.begin(), degrees.end());
+      const uint64_t p3    = p_low * p_low * p_low;
       const unsigned nr    = comm->n_ranks();
       const unsigned group = (nr >= 8 && nr % 4 == 0) ? 4 : ((nr >= 4 && nr % 2 == 0) ? 2 : 1);
-      partition            = std::make_unique<Partition>(triangulations, nr, 2.0, (uint64_t)4000000 / p3, group, (uint64_t)1000000 / p3);
+      partition            = std::make_unique<Partition>(mesh_sequence, nr, 2.0, (uint64_t)4000000 / p3, group, (uint64_t)1000000 / p3);
       sub_comm             = comm->subset(partition->group());
     }
-  auto distributed = [&](unsigned l) { return comm && comm->n_ranks() > 1 && l >= partition->sub_root_level(); };
-  auto level_comm  = [&](unsigned l) -> const Communicator  *{ return l >= partition->root_level() ? comm : &sub_comm; };
+  // (by mesh index: what the partition knows)
+  auto mesh_distributed = [&](unsigned mi) { return comm && comm->n_ranks() > 1 && mi >= partition->sub_root_level(); };
+  auto mesh_comm        = [&](unsigned mi) -> const Communicator        *{ return mi >= partition->root_level() ? comm : &sub_comm; };
+  auto distributed      = [&](unsigned l) { return mesh_distributed(mesh_index[l]); };
+  auto level_comm       = [&](unsigned l) { return mesh_comm(mesh_index[l]); };
 
   const bool hp_local        = params.type == "HPMG-local";
   PreconditionChebyshev::AdditionalData sd;
@@ -383,7 +399,7 @@ run(const Context &ctx, const RunParameters &params, ConvergenceTable &table, co
     if (hp_local && l == 0)
       dof_handlers.push_back(*ls_active); // the SAME DoFs as the local-smoothing cycle acts on
     else if (comm)
-      dof_handlers.emplace_back(*partition, l, comm->rank(), degrees[l]);
+      dof_handlers.emplace_back(*partition, mesh_index[l], comm->rank(), degrees[l]);
     else
       dof_handlers.emplace_back(triangulations[l], degrees[l], -1, local_smoothing);
   std::unique_ptr<DoFHandler> active_dof_handler;
@@ -405,7 +421,9 @@ run(const Context &ctx, const RunParameters &params, ConvergenceTable &table, co
   // CoarseGridSolverType "gmg_vcycle" (this project's extension) selects the geometric stand-in of rounds 1-2 instead: V-cycles
   // of the h-multigrid on that level.  The table says what ran in its `coarse_solver` column.
   const std::string coarse = hp_local ? std::string("gmg_vcycle") : params.mg_data.coarse_solver.type;
-  const bool amg_like      = !hp_local && coarse == "gmg_vcycle";
+  // (a SHARDED coarse level takes the geometric stand-in for the AMG choices too: the AMG is built from one rank's matrix)
+  const bool amg_name = coarse == "amg" || coarse == "cg_with_amg" || coarse == "amg_petsc";
+  const bool amg_like = !hp_local && (coarse == "gmg_vcycle" || (comm && distributed(0) && amg_name));
   std::vector<DoFHandler>            c_dof_handlers;
   std::vector<Operator>              c_operators;
   std::vector<MGTwoLevelTransfer>    c_transfers;
@@ -418,10 +436,18 @@ run(const Context &ctx, const RunParameters &params, ConvergenceTable &table, co
       c_operators.resize(nc);
       c_transfers.resize(nc);
       c_smoothers.resize(nc);
+      if (comm && nc != mesh_index[0] + 1)
+        throw std::runtime_error("sharded harness: the coarse level's mesh is not the end of the partition's mesh sequence");
       for (unsigned l = 0; l + 1 < nc; ++l)
-        c_dof_handlers.emplace_back(c_trias[l], degrees[0]);
+        if (comm)
+          c_dof_handlers.emplace_back(*partition, l, comm->rank(), degrees[0]); // (mesh index = level of the coarse hierarchy)
+        else
+          c_dof_handlers.emplace_back(c_trias[l], degrees[0]);
       for (unsigned l = 0; l + 1 < nc; ++l)
-        c_operators[l].reinit(ctx, c_dof_handlers[l], level_number_type);
+        if (comm)
+          c_operators[l].reinit(ctx, c_dof_handlers[l], level_number_type, mesh_distributed(l) ? mesh_comm(l) : nullptr);
+        else
+          c_operators[l].reinit(ctx, c_dof_handlers[l], level_number_type);
       c_operators[nc - 1] = operators[0];
       for (unsigned l = 1; l < nc; ++l)
         c_transfers[l].reinit(c_operators[l], c_operators[l - 1]);

@@ -160,3 +160,25 @@ def test_error_behaviour(tmp_path, key, value, message):
 def test_no_arguments():
     rc, out, err = run_harness()
     assert rc == 1 and "No .json parameter files" in out
+
+
+@pytest.mark.parametrize("mg_type,coarse", [("HMG-global", "amg"), ("PMG", "cg_with_chebyshev"), ("PMG", "amg"), ("HPMG", "amg")])
+def test_sharded_mode_with_one_rank_over_rccl(tmp_path, mg_type, coarse):
+    """One process per GPU (ref:multigrid_throughput.cc:2403-2442 is an MPI program): MGAMD_HARNESS_SHARDED=1 runs the sharded code
+    path -- RCCL communicator from the id file, Partition (two tiers), DoFHandler(partition, mesh, rank, degree),
+    Operator::reinit(..., comm), the geometric stand-in on a sharded AMG coarse level -- with the one rank a one-GPU box can run (RCCL
+    refuses two ranks on one device): same table as the plain run."""
+    base = json.load(open(os.path.join(GOLDEN, "input_0003.json")))
+    cfg = dict(base, Type=mg_type, GeometryType="annulus", NRefGlobal=6, Degree=2, MGNumberType="double", CoarseSolverNCycles=1,
+               CoarseGridSolverType=coarse)
+    f = str(tmp_path / "sharded.json")
+    json.dump(cfg, open(f, "w"))
+    rc, out, err = run_harness(f)
+    assert rc == 0, err
+    _, plain = final_table(out)
+    env = dict(os.environ, MGAMD_HARNESS_SHARDED="1", MGAMD_RCCL_ID_FILE=str(tmp_path / "rccl_id"), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([BIN, f], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr
+    _, sharded = final_table(r.stdout)
+    for key in ("n_cells", "n_dofs", "n_levels", "n_iterations", "sub_comm_size", "coarse_solver"):
+        assert sharded[0][key] == plain[0][key], key
