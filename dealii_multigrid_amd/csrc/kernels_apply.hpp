@@ -365,6 +365,10 @@ namespace mgamd
     T *bufA = reinterpret_cast<T *>(smem_raw);
     T *bufB = bufA + G::N3;
     T *dtab = bufB + G::N3; // [P^3] s = d/h, [P^3] 1/s
+    T *Etab = dtab + 2 * P * P * P + 1; // constrained bricks: the embedding E = [I0; I1] for brick_face_passes
+    // hanging-node passes node by node over the hanging faces (brick_face_passes) instead of line by line
+    // (P >= 2: at p = 1 the line form is cheap -- 3 x 2 weights -- and faster: octant p = 1 L = 9 1.37 ms against 1.58 ms with the node form)
+    constexpr bool FACE_PASSES = CONSTR && P >= 2 && B > 2 && face_table_words<P, B>() > 0 && G::N * (G::N - 2) <= G::ABLOCK;
 
     constexpr int BLOCK = G::ABLOCK;
     constexpr int ITER  = (G::N_INT + BLOCK - 1) / BLOCK;
@@ -378,6 +382,12 @@ namespace mgamd
     if (w >= n)
       return;
 
+    if constexpr (FACE_PASSES)
+      for (int t = tid; t < (2 * P + 1) * (P + 1); t += BLOCK)
+        {
+          const int a = t / (P + 1), b = t % (P + 1);
+          Etab[t]     = a <= P ? args.m.I0[a * (P + 1) + b] : args.m.I1[(a - P) * (P + 1) + b];
+        }
     if (is_cheb(MODE))
       {
         for (int t = tid; t < P3; t += BLOCK)
@@ -658,13 +668,23 @@ namespace mgamd
             // constrained bricks: whole-face / whole-edge hanging nodes (uniform branch: one mask per slot)
             any_hanging = fmcur != 0;
             if (any_hanging)
-              brick_constraint_passes<T, P, B, BLOCK>(bufA, args.m, tid, 1, args.g.fmask + slot, false, &fmcur);
+              {
+                if constexpr (FACE_PASSES)
+                  brick_face_passes<T, P, B, BLOCK>(bufA, Etab, (uint32_t)__builtin_amdgcn_readfirstlane((int)fmcur), tid, false);
+                else
+                  brick_constraint_passes<T, P, B, BLOCK>(bufA, args.m, tid, 1, args.g.fmask + slot, false, &fmcur);
+              }
           }
         // cell prefetch in the streamed sweeps (-4 % on the 2-4-word passes); the 5-word mode has no registers left for it
         lattice_sweeps<T, P, B, BLOCK, NoHook, true, (MODE != MODE_CHEB || sizeof(T) == 4)>(bufA, bufB, args.m, tid, 1, &hcur);
         if constexpr (brick_may_be_constrained(B, CONSTR))
           if (any_hanging)
-            brick_constraint_passes<T, P, B, BLOCK>(bufA, args.m, tid, 1, args.g.fmask + slot, true, &fmcur);
+            {
+              if constexpr (FACE_PASSES)
+                brick_face_passes<T, P, B, BLOCK>(bufA, Etab, (uint32_t)__builtin_amdgcn_readfirstlane((int)fmcur), tid, true);
+              else
+                brick_constraint_passes<T, P, B, BLOCK>(bufA, args.m, tid, 1, args.g.fmask + slot, true, &fmcur);
+            }
         MGAMD_STAMP(2)
 
         // ---- values of the next slot: requested now, consumed at the top of the next iteration ------------------

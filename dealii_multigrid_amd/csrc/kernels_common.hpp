@@ -869,6 +869,116 @@ namespace mgamd
       }
   }
 
+  // The same passes for ONE constrained brick per workgroup (N^2 >= 256 lines: the 17-point lattices), node by node over the
+  // brick's hanging faces.  The line form above gives every hanging line to one thread -- 17 of 256 threads busy per hanging face
+  // and direction, each with a serial chain of 17 loads, 18 (P + 1) multiply-adds and 17 stores whose weights stream through the
+  // scalar registers -- and was the reason why constrained 4^3 bricks at p = 4 cost twice a plain brick (rounds 2 and 3).  Here,
+  // per direction d:
+  //   faces   each of the (up to four) hanging faces that contain d: its N (N - 2) nodes on lines STRICTLY inside the face,
+  //           thread t -> (line t / N, node t % N): one round of 255 threads at N = 17
+  //   edges   the four lattice edges along d: 4 N nodes; an edge line is hanging if one of its two faces is, or the edge itself
+  // every node needs P + 1 (forward) or up to 2 (2 P + 1) (transposed) multiply-adds with weights E = [I0; I1] from LDS; the new
+  // values wait in registers for a barrier because the passes work in place.  fm is uniform in the workgroup.
+  template <int P, int B>
+  constexpr int
+  face_table_words() // LDS words (of the number type) behind the D^-1 table of the persistent brick kernel: E = [I0; I1]
+  {
+    return (B > 2 && (P * B + 1) * (P * B + 1) >= 256) ? (2 * P + 1) * (P + 1) : 0;
+  }
+  template <typename T, int P, int B, int BLOCK>
+  __device__ __forceinline__ void
+  brick_face_passes(T *__restrict__ buf, const T *__restrict__ E, const uint32_t fm, const int tid_in, const bool transpose)
+  {
+    constexpr int N = P * B + 1, n = P + 1, BC = B / 2;
+    static_assert(N * (N - 2) <= BLOCK && 4 * N <= BLOCK, "one round per face and one for the edges");
+    // an opaque copy of the thread index: everything below is invariant across the slots of a persistent workgroup, and the compiler
+    // would hoist the address arithmetic of all thirty node rounds out of the slot loop and spill it (measured: 30-140 spills)
+    int tid;
+    asm volatile("v_mov_b32_e32 %0, %1" : "=v"(tid) : "v"(tid_in));
+    // new value of the node at coordinate i of the line (base, stride)
+    auto node_value = [&](const int base, const int stride, const int i) -> T {
+      if (!transpose)
+        {
+          // fine node a of parent cell k from the cell's P + 1 parent values (b < P: at 2 k P + b; b = P: at 2 (k + 1) P)
+          const int k = min(i / (2 * P), BC - 1), a = i - 2 * k * P;
+          T         s = T(0);
+#pragma unroll
+          for (int b = 0; b < n; ++b)
+            s += E[a * n + b] * buf[base + (b < P ? 2 * k * P + b : 2 * (k + 1) * P) * stride];
+          return s;
+        }
+      // parent value b of parent cell k collects its column of E over the cell's fine nodes (a node shared by two cells counts
+      // once, with the lower cell); the other positions of the line become zero
+      const bool last = i == N - 1;
+      const int  k = last ? BC - 1 : i / (2 * P), r = i - 2 * k * P;
+      if (!last && r >= P)
+        return T(0);
+      const int b = last ? P : r;
+      T         s = T(0);
+#pragma unroll
+      for (int a = 0; a <= 2 * P; ++a)
+        if (a > 0 || k == 0)
+          s += E[a * n + b] * buf[base + (2 * k * P + a) * stride];
+      if (b == 0 && k > 0)
+        {
+#pragma unroll
+          for (int a = 0; a <= 2 * P; ++a)
+            if (a > 0 || k == 1)
+              s += E[a * n + P] * buf[base + (2 * (k - 1) * P + a) * stride];
+        }
+      return s;
+    };
+#pragma unroll
+    for (int dd = 0; dd < 3; ++dd)
+      {
+        const int d = transpose ? 2 - dd : dd;
+        const int e = d == 0 ? 1 : 0, f = d == 2 ? 1 : 2; // the other two directions, (u, v) as in brick_constraint_passes
+        const int sd = d == 0 ? 1 : (d == 1 ? N : N * N), se = e == 0 ? 1 : (e == 1 ? N : N * N), sf = f == 0 ? 1 : (f == 1 ? N : N * N);
+        const uint32_t he0 = (fm >> (2 * e)) & 1u, he1 = (fm >> (2 * e + 1)) & 1u, hf0 = (fm >> (2 * f)) & 1u, hf1 = (fm >> (2 * f + 1)) & 1u;
+        // edge along d at sides (s1 of (d+1)%3, s2 of (d+2)%3); (u, v) = coordinates in (e, f): d = 1 has (e, f) = (x, z) = ((d+2)%3, (d+1)%3)
+        auto edge_bit = [&](int su, int sv) -> uint32_t {
+          const int s1 = d == 1 ? sv : su, s2 = d == 1 ? su : sv;
+          return (fm >> (6 + 4 * d + s1 + 2 * s2)) & 1u;
+        };
+        const bool any = he0 | he1 | hf0 | hf1 | edge_bit(0, 0) | edge_bit(1, 0) | edge_bit(0, 1) | edge_bit(1, 1);
+        if (!any)
+          continue; // (uniform)
+        // (one face or the edges at a time: read, barrier, write, barrier -- a single new value per thread is live, the kernel has
+        // no registers to spare next to its pipeline state; only hanging entities cost anything: the branches are uniform)
+        const int line = tid / N + 1, i = tid % N;
+#pragma unroll
+        for (int q = 0; q < 5; ++q)
+          {
+            bool on = false;
+            int  base = 0;
+            if (q < 4)
+              {
+                // faces u = 0, u = N - 1 (lines at v = 1 .. N - 2), v = 0, v = N - 1 (lines at u = 1 .. N - 2)
+                const uint32_t h = q == 0 ? he0 : (q == 1 ? he1 : (q == 2 ? hf0 : hf1));
+                if (!h)
+                  continue; // (uniform)
+                const int u = q == 0 ? 0 : (q == 1 ? N - 1 : line), v = q == 2 ? 0 : (q == 3 ? N - 1 : line);
+                on   = tid < N * (N - 2);
+                base = u * se + v * sf;
+              }
+            else
+              {
+                // the four edges along d
+                const int c = tid / N, su = c & 1, sv = (c >> 1) & 1;
+                on   = tid < 4 * N && (((su ? he1 : he0) | (sv ? hf1 : hf0) | edge_bit(su, sv)) != 0u);
+                base = su * (N - 1) * se + sv * (N - 1) * sf;
+              }
+            T nv = T(0);
+            if (on)
+              nv = node_value(base, sd, i);
+            __syncthreads(); // every thread has read the old values of its line
+            if (on)
+              buf[base + i * sd] = nv;
+            __syncthreads();
+          }
+      }
+  }
+
   // ---- 1D embedding of the h-transfer along one lattice line (brick transfers and the transfers fused into the operator)
   // fine line (P*BC*2+1) from coarse line (P*BC+1), cell by cell
   template <typename T, int P, int BC>

@@ -99,7 +99,7 @@ namespace mgamd
       }
     else
       {
-        const size_t lds  = (2 * (size_t)G::SPW * G::N3 + 2 * P * P * P + G::SPW) * sizeof(T);
+        const size_t lds  = (2 * (size_t)G::SPW * G::N3 + 2 * P * P * P + G::SPW + face_table_words<P, B>()) * sizeof(T);
         if constexpr (G::SPW == 1 && G::N_INT > 0 && G::ROUNDS > 1)
           {
             // one-slot-per-workgroup lattices (17^3): persistent workgroups with a software pipeline over their slots
@@ -523,7 +523,7 @@ namespace mgamd
       pa.g_constrained = g_constrained->view();
       pa.n_wg_plain    = (uint32_t)((a.g.n_slots + G::SPW - 1) / G::SPW);
       const uint32_t n_wg_c = (uint32_t)((g_constrained->n_slots + G::SPW - 1) / G::SPW);
-      const size_t   lds    = (2 * (size_t)G::SPW * G::N3 + 2 * P * P * P + G::SPW) * sizeof(T);
+      const size_t   lds    = (2 * (size_t)G::SPW * G::N3 + 2 * P * P * P + G::SPW + face_table_words<P, B>()) * sizeof(T);
       if constexpr (G::SPW == 1 && G::N_INT > 0 && G::ROUNDS > 1)
         if (use_persistent<T, P>())
           {
@@ -581,7 +581,7 @@ namespace mgamd
                 return launch_pair<P, B, MODE>(st, a, partner_constrained);
               throw std::runtime_error("brick pair launch: size not instantiated");
             }
-          const size_t lds      = (2 * (size_t)G::N3 + 2 * P * P * P + 1) * sizeof(T);
+          const size_t lds      = (2 * (size_t)G::N3 + 2 * P * P * P + 1 + face_table_words<P, B>()) * sizeof(T);
           const int    resident = resident_workgroups(ctx, persistent_wgs_per_cu<T, P>());
           auto         kern     = lattice_apply_persistent_kernel<T, P, B, MODE>;
           ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), lds);
