@@ -44,3 +44,26 @@ def test_round3_kernel_paths_agree(tmp_path, geo, L, p):
     for key in ("ax", "step", "vcycle"):
         a, b = ref[key], alt[key]
         assert np.linalg.norm(a - b) <= 1e-12 * np.linalg.norm(a), key
+
+
+@pytest.mark.parametrize("geo,L,p", [("quadrant", 6, 4)])
+def test_constrained_rim_bricks_agree(tmp_path, geo, L, p):
+    """MGAMD_MAX_CONSTRAINED_BRICK=4 (development switch): the 4^3 bricks next to coarser cells stay 17-point
+    lattices with whole hanging faces / edges (persistent CONSTR kernel, hanging-node passes node by node over the faces:
+    brick_face_passes) instead of eight families each -- same operator, smoother step and V-cycle to rounding.  The slot
+    decomposition changes the DoF numbering, so inputs and results are matched through the geometric DoF keys."""
+    def run_keys(out, env_extra):
+        env = dict(os.environ, MGAMD_CHEB_KEY_INIT="1")  # numbering-independent Chebyshev start vector
+        env.update(env_extra)
+        subprocess.run([sys.executable, os.path.join(HERE, "_vcycle_dump.py"), geo, str(L), str(p), out, "keys"], check=True, env=env, timeout=600)
+        return np.load(out)
+
+    ref = run_keys(str(tmp_path / "default.npz"), {})
+    alt = run_keys(str(tmp_path / "alt.npz"), {"MGAMD_MAX_CONSTRAINED_BRICK": "4"})
+    assert sum(1 for g in alt["groups"] if g[0] == 4 and g[1] > 0) == 2 > sum(1 for g in ref["groups"] if g[0] == 4 and g[1] > 0)
+    order = lambda d: np.lexsort(d["keys"].T[::-1])
+    ro, ao = order(ref), order(alt)
+    assert np.array_equal(ref["keys"][ro], alt["keys"][ao])
+    for key in ("ax", "step", "vcycle"):
+        a, b = ref[key][ro], alt[key][ao]
+        assert np.linalg.norm(a - b) <= 1e-11 * np.linalg.norm(a), key
