@@ -116,3 +116,50 @@ def test_random_octree_sharded(mgamd, oracle, seed, n_global, rounds, fraction, 
         assert rel_err(o["z"], zref[o["idx"]]) < 1e-11
         assert o["it"] == itref
         assert rel_err(o["x"], xref[o["idx"]]) < 1e-10
+
+
+@pytest.mark.parametrize("seed,n_global,rounds,fraction,p,mg_type", [(3, 3, 1, 0.01, 4, "PMG"), (5, 2, 2, 0.05, 4, "HPMG"), (6, 2, 3, 0.02, 2, "PMG"),
+                                                                    (7, 3, 1, 0.0, 4, "HPMG")])
+def test_random_octree_p_multigrid(mgamd, oracle, ctx, seed, n_global, rounds, fraction, p, mg_type):
+    """polynomial (PMG) and hybrid (HPMG) coarsening on caller-built random octrees: the p-transfers between levels that share
+    the mesh, and for HPMG the h-levels below them, against the numpy oracle (coarse level small enough for the exact solve)"""
+    leaves = random_mesh(oracle, seed, n_global, rounds, fraction)
+    arr = np.array(sorted(leaves), dtype=np.int64)
+    tria = mgamd.Triangulation.from_leaves(arr[:, 0], arr[:, 1], arr[:, 2], arr[:, 3])
+    h = mgamd.Hierarchy(ctx, tria, None, p, mg_type, coarse_solver="amg")
+    assert h.mg.coarse_solver_used() == "direct"
+    pseq = [p]
+    while pseq[-1] > 1:
+        pseq.append(max(pseq[-1] // 2, 1))
+    pseq = pseq[::-1]
+    if mg_type == "PMG":
+        meshes, degs = [leaves] * len(pseq), pseq
+    else:
+        hm = oracle.coarsening_sequence(leaves)
+        meshes, degs = hm + [leaves] * (len(pseq) - 1), [pseq[0]] * len(hm) + pseq[1:]
+    assert [d.degree for d in h.dofs] == degs and [t.n_cells for t in h.trias] == [len(m) for m in meshes]
+    levels = [oracle.Level(m, q, d.keys()) for m, q, d in zip(meshes, degs, h.dofs)]
+    P = [None] + [oracle.build_transfer(levels[l], levels[l - 1]) for l in range(1, len(levels))]
+    omg = oracle.Multigrid(levels, P, 3, coarse="direct")
+    Lf = levels[-1]
+    rng = np.random.default_rng(200 + seed)
+    for l in range(1, len(levels)):
+        xc, xf0 = rng.standard_normal(levels[l - 1].n), rng.standard_normal(levels[l].n)
+        vc, vf = h.operators[l - 1].initialize_dof_vector().from_host(xc), h.operators[l].initialize_dof_vector().from_host(xf0)
+        h.transfers[l].prolongate_and_add(vf, vc)
+        assert rel_err(vf.to_host(), xf0 + P[l] @ xc) < 1e-13
+        rf, dc0 = rng.standard_normal(levels[l].n), rng.standard_normal(levels[l - 1].n)
+        vr, vd = h.operators[l].initialize_dof_vector().from_host(rf), h.operators[l - 1].initialize_dof_vector().from_host(dc0)
+        h.transfers[l].restrict_and_add(vd, vr)
+        assert rel_err(vd.to_host(), dc0 + P[l].T @ rf) < 1e-13
+    r = rng.standard_normal(Lf.n)
+    r[Lf.constrained] = 0.0
+    vr, vz = mgamd.Vector(ctx, Lf.n).from_host(r), mgamd.Vector(ctx, Lf.n)
+    h.mg.vmult(vz, vr)
+    assert rel_err(vz.to_host(), omg.vcycle(r)) < 1e-11
+    xref, itref, hist = oracle.pcg(Lf.A, Lf.rhs_constant, omg.vcycle, 1e-4)
+    b, x = h.fine_operator.initialize_dof_vector(), h.fine_operator.initialize_dof_vector()
+    h.fine_operator.rhs(b)
+    it, res = mgamd.solve_cg(h.fine_operator, h.mg, x, b, 1e-4)
+    assert it == itref
+    assert rel_err(x.to_host(), xref) < 1e-10
