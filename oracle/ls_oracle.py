@@ -80,7 +80,8 @@ class LSLevel:
 
 class LocalSmoothing:
     def __init__(self, geometry, n_ref_global, degree, smoother_degree=3, numbering_keys_global=None, numbering_keys_levels=None):
-        leaves = o.create_mesh(geometry, n_ref_global)
+        # (geometry may be a set of leaves: a caller-built, 2:1-balanced octree)
+        leaves = set(geometry) if isinstance(geometry, (set, frozenset)) else o.create_mesh(geometry, n_ref_global)
         self.G = o.Level(leaves, degree, numbering_keys_global)  # the outer (active mesh) problem
         S = level_meshes(leaves)
         nk = numbering_keys_levels or [None] * len(S)

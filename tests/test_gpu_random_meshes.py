@@ -163,3 +163,34 @@ def test_random_octree_p_multigrid(mgamd, oracle, ctx, seed, n_global, rounds, f
     it, res = mgamd.solve_cg(h.fine_operator, h.mg, x, b, 1e-4)
     assert it == itref
     assert rel_err(x.to_host(), xref) < 1e-10
+
+
+@pytest.mark.parametrize("seed,n_global,rounds,fraction,p", [(2, 3, 1, 0.02, 2), (6, 2, 3, 0.02, 2), (1, 3, 2, 0.02, 1), (5, 2, 2, 0.05, 4)])
+def test_random_octree_local_smoothing(mgamd, oracle, ctx, seed, n_global, rounds, fraction, p):
+    """HMG-local (solve_with_local_smoothing, ref:multigrid_throughput.cc:1670-1873) on caller-built random octrees: refinement
+    levels with several disconnected refined regions and refinement edges of every shape -- level meshes, edge matrices,
+    copy indices, V-cycle (symmetric) and solve against oracle/ls_oracle.py on the same leaves"""
+    import ls_oracle
+
+    leaves = random_mesh(oracle, seed, n_global, rounds, fraction)
+    arr = np.array(sorted(leaves), dtype=np.int64)
+    tria = mgamd.Triangulation.from_leaves(arr[:, 0], arr[:, 1], arr[:, 2], arr[:, 3])
+    h = mgamd.Hierarchy(ctx, tria, None, p, "HMG-local", coarse_solver="amg")
+    ref = ls_oracle.LocalSmoothing(leaves, None, p, numbering_keys_global=h.active_dofs.keys(), numbering_keys_levels=[d.keys() for d in h.dofs])
+    n = ref.G.n
+    assert h.n_dofs == n and h.mg.coarse_solver_used() == "direct" and any(d.info.n_edge for d in h.dofs)
+    rng = np.random.default_rng(300 + seed)
+    r, u = rng.standard_normal(n), rng.standard_normal(n)
+    r[ref.G.constrained] = 0.0
+    u[ref.G.constrained] = 0.0
+    vr, vz, vu, vw = (mgamd.Vector(ctx, n) for _ in range(4))
+    vr.from_host(r), vu.from_host(u)
+    h.mg.vmult(vz, vr)
+    h.mg.vmult(vw, vu)
+    assert rel_err(vz.to_host(), ref.vcycle(r)) < 1e-11
+    assert abs(u @ vz.to_host() - r @ vw.to_host()) < 1e-10 * abs(u @ vz.to_host())  # a symmetric preconditioner
+    xref, itref, hist = ref.solve(1e-4)
+    b, x = h.fine_operator.initialize_dof_vector(), h.fine_operator.initialize_dof_vector()
+    h.fine_operator.rhs(b)
+    it, res = mgamd.solve_cg(h.fine_operator, h.mg, x, b, 1e-4)
+    assert it == itref and rel_err(x.to_host(), xref) < 1e-10
