@@ -13,10 +13,19 @@ MARKER_N = 77777  # vec_set on a vector of this length = the marker dispatch
 geo, L, p = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 cycles = int(sys.argv[4]) if len(sys.argv) > 4 else 5
 mg_type = sys.argv[5] if len(sys.argv) > 5 else "HMG-global"
+coarse = sys.argv[6] if len(sys.argv) > 6 else ("amg" if mg_type == "HMG-global" else "cg_with_chebyshev")
+coarse_cycles = int(sys.argv[7]) if len(sys.argv) > 7 else 1
+number_type = m.F32 if os.environ.get("MGAMD_TRACE_FLOAT") else m.F64  # MGNumberType float: FP32 levels under FP64 outer vectors
 ctx = m.Context(0)
-h = m.Hierarchy(ctx, geo, L, p, mg_type, coarse_solver="amg" if mg_type == "HMG-global" else "cg_with_chebyshev")
-b, z = h.fine_operator.initialize_dof_vector(), h.fine_operator.initialize_dof_vector()
-h.fine_operator.rhs(b)
+h = m.Hierarchy(ctx, geo, L, p, mg_type, coarse_solver=coarse, coarse_n_cycles=coarse_cycles, number_type=number_type)
+if number_type == m.F64:
+    b, z = h.fine_operator.initialize_dof_vector(), h.fine_operator.initialize_dof_vector()
+    h.fine_operator.rhs(b)
+else:
+    import numpy as np
+
+    b, z = m.Vector(ctx, h.dofs[-1].n_dofs), m.Vector(ctx, h.dofs[-1].n_dofs)
+    b.from_host(np.asarray(h.dofs[-1].rhs_constant()))
 marker = m.Vector(ctx, MARKER_N)
 # calibration dispatches for the PMC summaries (tools/pmc_vcycle.py): y = s y + a x on 32 M doubles reads 2 words and
 # writes 1 word per entry
