@@ -304,7 +304,10 @@ namespace mgamd
                   const T xov = MODE == MODE_CHEB_SECOND ? args.epi.c0 * dv * bv[it] : xo[it];
                   r           = xg[it] + args.epi.f1 * (xg[it] - xov) + args.epi.f2 * dv * (bv[it] - ax);
                 }
-              NT_STORE(r, &args.epi.out[e.g]);
+              if (MODE == MODE_CHEB)
+                store_result(args.epi, e.g, r);
+              else
+                NT_STORE(r, &args.epi.out[e.g]);
             }
       }
     MGAMD_STAMP(3)
@@ -777,7 +780,10 @@ namespace mgamd
                       else
                         r = xv + args.epi.f1 * (xv - xov) + args.epi.f2 * dv * (bv[it] - ax);
                     }
-                  NT_STORE(r, &args.epi.out[g]);
+                  if (MODE == MODE_CHEB && !FUSE_P)
+                    store_result(args.epi, g, r);
+                  else
+                    NT_STORE(r, &args.epi.out[g]);
                 }
             MGAMD_STAMP(3)
             // ---- shell DoFs: partial sums into the tail accumulator ------------------------------------------------
@@ -1397,7 +1403,13 @@ namespace mgamd
                 else if (MODE == MODE_RESIDUAL)
                   NT_STORE(bv[u] - ax[u], &epi.out[gi]);
                 else if (is_cheb(MODE))
-                  NT_STORE(xv[u] + epi.f1 * (xv[u] - xo[u]) + epi.f2 * dv[u] * (bv[u] - ax[u]), &epi.out[gi]);
+                  {
+                    const T r = xv[u] + epi.f1 * (xv[u] - xo[u]) + epi.f2 * dv[u] * (bv[u] - ax[u]);
+                    if (MODE_ == MODE_CHEB)
+                      store_result(epi, gi, r);
+                    else
+                      NT_STORE(r, &epi.out[gi]);
+                  }
                 else
                   epi.out[gi] = (i < n_tail && fabs((double)ax[u]) > 1.0e-10) ? T(1) / ax[u] : T(1);
               }

@@ -129,7 +129,21 @@ namespace mgamd
     const uint8_t *xs_flag = nullptr;
     const T       *xs      = nullptr;
     T             *x_inout = nullptr;
+    // MODE_CHEB only, float levels under double outer vectors (MGNumberType float): the LAST post-smoothing pass of the finest
+    // level stores its result as doubles here instead of `out` -- copy_from_mg (ref:multigrid_throughput.cc:1201-1203) without a
+    // pass of its own over the 137 M-DoF vectors
+    double *out_wide = nullptr;
   };
+  // the store of a Chebyshev result (interior and tail epilogues)
+  template <typename T>
+  __device__ __forceinline__ void
+  store_result(const Epilogue<T> &e, const uint32_t g, const T r)
+  {
+    if (sizeof(T) == 4 && e.out_wide != nullptr) // (uniform; never taken by the double kernels)
+      __builtin_nontemporal_store((double)r, &e.out_wide[g]);
+    else
+      __builtin_nontemporal_store(r, &e.out[g]);
+  }
   constexpr bool
   is_cheb(int mode)
   {

@@ -826,10 +826,15 @@ namespace mgamd
     }
 
     void
-    cheb_raw(T *out, const T *x, const T *xold, const T *b, const T *dinv, double f1, double f2, int from_b = 0, double c0 = 0.0)
+    cheb_raw(T *out, const T *x, const T *xold, const T *b, const T *dinv, double f1, double f2, int from_b = 0, double c0 = 0.0,
+             double *out_wide = nullptr)
     {
       // from_b = 1: x is c0 dinv b and xold = 0 (x is not read); from_b = 2: xold is c0 dinv b (xold is not read)
+      // out_wide (float levels, plain Chebyshev pass only): the result goes there as doubles, `out` is not written
       Epilogue<T> e{out, x, from_b ? nullptr : xold, b, dinv, T(f1), T(f2), T(c0)};
+      if (out_wide && (from_b != 0 || sizeof(T) != 4))
+        throw std::invalid_argument("cheb_raw: a wide result needs a plain Chebyshev pass on float vectors");
+      e.out_wide = out_wide;
       if (dinv == dinv_coded && dinv_code.p)
         {
           e.dinv_code  = dinv_code.p;

@@ -507,8 +507,11 @@ namespace mgamd
     // general initial guess x0 in X; O is scratch; returns the buffer holding the result.  prolongate != nullptr: the initial
     // guess is X + P x_c with the prolongation fused into the first operator pass (X becomes X + P x_c on the way)
     T *
-    step_raw(T *X, T *O, const T *b, const FusedTransferHost<T> *prolongate = nullptr)
+    step_raw(T *X, T *O, const T *b, const FusedTransferHost<T> *prolongate = nullptr, double *out_wide = nullptr)
     {
+      // out_wide (float levels): the result is wanted there as doubles; nullptr is returned.  With a plain Chebyshev pass at the end
+      // (degree >= 2) that pass stores the doubles itself, otherwise a cast follows
+      const bool wide_in_pass = out_wide && degree >= 2 && std::fabs(delta) >= 1e-40 && sizeof(T) == 4;
       T *cur = X, *oth = O;
       if (prolongate)
         lop->cheb_prolongate_raw(oth, cur, b, dinv.p, 1.0 / theta, *prolongate);
@@ -523,11 +526,14 @@ namespace mgamd
               const double rhokp = 1.0 / (2.0 * sigma - rhok);
               const double f1 = rhokp * rhok, f2 = 2.0 * rhokp / delta;
               rhok = rhokp;
-              lop->cheb_raw(oth, cur, oth, b, dinv.p, f1, f2);
+              const bool last = j + 2 == degree;
+              lop->cheb_raw(oth, cur, oth, b, dinv.p, f1, f2, 0, 0.0, (last && wide_in_pass) ? out_wide : nullptr);
               std::swap(cur, oth);
             }
         }
-      return cur;
+      if (out_wide && !wide_in_pass)
+        hipLaunchKernelGGL((vec_copy_kernel<double, T>), grid_for(lop->n_dofs()), 256, 0, lop->ctx->stream, out_wide, cur, lop->n_dofs());
+      return out_wide ? nullptr : cur;
     }
 
     void
@@ -1229,6 +1235,8 @@ namespace mgamd
     std::vector<LevelOperator<T> *>  ops;
     std::vector<Transfer2<T> *>      tr;
     std::vector<Chebyshev<T> *>      sm;
+    double *wide_out          = nullptr;                                  // see vcycle_raw: the outer result vector while a cycle runs
+    bool    wide_copy_from_mg = getenv("MGAMD_NO_WIDE_COPY_FROM_MG") == nullptr; // development switch
     std::vector<std::unique_ptr<DBuf<T>>> defect, S, Tb, res; // defect: only the finest level owns memory,
     DBuf<T>                               defect_slab;        // the coarser defects share one slab (ONE memset per cycle)
     std::vector<T *>                      dptr;               // defect vector of every level
@@ -1722,15 +1730,17 @@ namespace mgamd
         }
       stage(5, false, l);
       stage(6, true, l);
+      // (finest level of float levels under double outer vectors: the last pass writes the doubles of copy_from_mg itself)
+      double *wide = (l == nl - 1) ? wide_out : nullptr;
       if (fuse)
         {
           FusedTransferHost<T> f = tr[l]->fused;
           f.coarse               = sol[l - 1];
           f.scratch              = res[l]->p; // the residual vector is free again
-          sol[l]                 = sm[l]->step_raw(sview[l], tview[l], dview[l], &f);
+          sol[l]                 = sm[l]->step_raw(sview[l], tview[l], dview[l], &f, wide);
         }
       else
-        sol[l] = sm[l]->step_raw(sview[l], tview[l], dview[l]); // post-smoothing
+        sol[l] = sm[l]->step_raw(sview[l], tview[l], dview[l], nullptr, wide); // post-smoothing
       stage(6, false, l);
     }
 
@@ -1805,10 +1815,18 @@ namespace mgamd
       if (nl > 1)
         defect_slab.zero(ctx->stream);
       stage(7, false, L);
+      // copy_from_mg inside the last post-smoothing pass (Epilogue::out_wide): float levels, double outer vectors, a smoother of
+      // degree >= 2 (its last pass is a plain Chebyshev pass), no stage callbacks (they want the reference's separate stages)
+      wide_out = nullptr;
+      if constexpr (sizeof(T) == 4 && sizeof(TO) == 8)
+        if (nl > 1 && !cb && wide_copy_from_mg)
+          wide_out = reinterpret_cast<double *>(z);
       level_v_step(L);
       stage(8, true, L);
-      if ((const void *)sol[L] != (const void *)z)
+      // (sol[L] == nullptr: the last smoothing pass has written z; a collapsed finest level leaves its result in a level vector)
+      if (sol[L] != nullptr && (const void *)sol[L] != (const void *)z)
         hipLaunchKernelGGL((vec_copy_kernel<TO, T>), grid_for(n), 256, 0, ctx->stream, z, sol[L], n);
+      wide_out = nullptr;
       stage(8, false, L);
     }
 
